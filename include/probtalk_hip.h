@@ -1,0 +1,117 @@
+/* probtalk_hip.h — C ABI of libprobtalk_hip.so, the MI355X (gfx950) implementation of ProbTalk's
+ * token hot path (PQ-VAE encode/quantize/decode, predictor MaskGIT transformer, refiner transformer).
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, non-zero on error; pt_last_error() returns the message (thread local);
+ *   - tensor pointers are DEVICE pointers to contiguous fp32 data in the reference's own layout
+ *     (NCL for (B,C,T) tensors) unless a parameter says otherwise; int tensors as documented;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*), nothing synchronises;
+ *   - no entry point below the "model lifetime" block allocates: scratch comes from the caller's
+ *     `ws` buffer of at least pt_*_workspace_bytes() bytes; outputs are caller allocated;
+ *   - citations `file:line` name the reference interface (feifeifeiliu/probtalk @ 2024_08_07) that
+ *     the entry point replaces.
+ */
+#ifndef PROBTALK_HIP_H
+#define PROBTALK_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pt_model pt_model;
+
+const char* pt_last_error(void);
+int pt_version(void);
+
+/* ---- model lifetime (may allocate) --------------------------------------------------------- */
+/* kind / cfg:
+ *   "vqvae_sc"     {in_dim, emb_dim, num_codes, num_hiddens, groups, 4}   nets/inpainting/vqvae_1d_sc.py:277-298
+ *   "vqvae_legacy" {in_dim, emb_dim, num_codes, num_hiddens, 1, 3}        nets/spg/vqvae_1d.py:147-161
+ *   "cond_encoder" {in_dim, num_hiddens}                                  nets/inpainting/vqvae_1d_sc.py:70-84
+ *   "predictor"    {mot_dim, num_codes, groups, n_classes, n_layers, audio_dim}  nets/inpainting/predictornet.py:13-59
+ *   "refiner"      {in_dim, cond_dim, n_classes, n_layers}                nets/inpainting/RTransformer.py:181-207 */
+pt_model* pt_model_create(const char* kind, const int* cfg, int ncfg);
+/* Hand over one state_dict entry (HOST pointer, copied): the reference's own key names and layouts,
+ * i.e. what `module.state_dict()` / a ckpt-*.pth holds (vq_teacher.py:103-114, predictor.py:128-143).
+ * dtype: 0 = float32, 1 = float64 (positional-encoding tables). */
+int pt_model_set_tensor(pt_model* m, const char* name, const void* host_data, const int64_t* shape, int ndim, int dtype);
+/* Fold BatchNorm(eval) into the convs, repack, upload.  Replaces nn.Module.load_state_dict + .to(device). */
+int pt_model_finalize(pt_model* m);
+void pt_model_destroy(pt_model* m);
+
+/* ---- PQ-VAE ------------------------------------------------------------------------------- */
+size_t pt_vqvae_workspace_bytes(const pt_model* m, int B, int T);
+/* VQVAE_SC.encode (vqvae_1d_sc.py:317-320) + ProductQuantization.forward eval (vqvae_modules.py:470-492):
+ * x (B,in_dim,T) -> z (B,emb,T') [optional], quantized (B,emb,T') [optional], indices (B,T',G) int64.
+ * Legacy VQVAE.encode (vqvae_1d.py:175-178) with kind "vqvae_legacy" (G = 1). */
+int pt_vqvae_encode(pt_model* m, const float* x, int B, int T, float* z, float* quantized, int64_t* indices,
+                    void* ws, size_t ws_bytes, void* stream);
+/* VQVAE_SC.decode (vqvae_1d_sc.py:322-324): e (B,emb,T') -> out (B,in_dim,8T'). */
+int pt_vqvae_decode(pt_model* m, const float* e, int B, int Tq, float* out, void* ws, size_t ws_bytes, void* stream);
+/* quantize_all + transpose + decode (predictor.py:439-442; demo.py:152-153): codes (B,T',G) -> out. */
+int pt_vqvae_decode_codes(pt_model* m, const void* codes, int codes_are_int64, int B, int Tq, float* out, void* ws,
+                          size_t ws_bytes, void* stream);
+/* ProductQuantization.forward eval on a caller-supplied latent: z (B,emb,W) -> quantized (B,emb,W), indices (B,W,G). */
+int pt_pq_quantize(pt_model* m, const float* z, int B, int W, float* quantized, int64_t* indices, void* ws,
+                   size_t ws_bytes, void* stream);
+/* ProductQuantization.quantize_all (vqvae_modules.py:557-564): idx (rows,G) -> out (rows, emb) row-major. */
+int pt_pq_quantize_all(pt_model* m, const void* idx, int idx_are_int64, int rows, float* out, void* stream);
+
+/* ---- audio condition encoder -------------------------------------------------------------- */
+size_t pt_cond_encoder_workspace_bytes(const pt_model* m, int B, int T);
+/* ConditionEncoder.forward (vqvae_1d_sc.py:86-91): aud (B,768,T) -> (B,256,T/8). */
+int pt_cond_encoder_forward(pt_model* m, const float* aud, int B, int T, float* out, void* ws, size_t ws_bytes,
+                            void* stream);
+
+/* ---- predictor ---------------------------------------------------------------------------- */
+size_t pt_predictor_workspace_bytes(const pt_model* m, int B, int T);
+/* PredictorNet.forward up to the decoder call (predictornet.py:87-100):
+ * masked_motion (B,mot,T), mask (B,1,T), audio (B,256,T') -> condition (B,768,T'). */
+int pt_predictor_condition(pt_model* m, const float* masked_motion, const float* mask, const float* audio, int B, int T,
+                           float* condition, void* ws, size_t ws_bytes, void* stream);
+/* PTransformer.tokens_to_logits (PTransformer.py:657-694): ids (B,T',G) int32 (mask id = num_codes),
+ * label (B) int64, condition (B,768,T') -> logits (B,T',G,num_codes). */
+int pt_predictor_logits(pt_model* m, const int32_t* ids, const int64_t* label, const float* condition, int B, int Tq,
+                        float* logits, void* ws, size_t ws_bytes, void* stream);
+/* PTransformer.sample_good (PTransformer.py:590-642): the whole MaskGIT loop with the two random draws
+ * injected: noise_q (steps,B,N,num_codes) ~ Exp(1) for the categorical draw, noise_g (steps,B,N) ~ Gumbel(0,1).
+ * codes_out (B,T',G) int32.  logits_out (steps,B,N,num_codes) optional (may be NULL). */
+int pt_predictor_sample(pt_model* m, const int64_t* label, const float* condition, const float* noise_q,
+                        const float* noise_g, int steps, int B, int Tq, int32_t* codes_out, float* logits_out, void* ws,
+                        size_t ws_bytes, void* stream);
+
+/* ---- refiner ------------------------------------------------------------------------------ */
+size_t pt_refiner_workspace_bytes(const pt_model* m, int B, int T);
+/* RTransformer.forward (RTransformer.py:209-230): x (B,in,T), condition (B,768,T), mask (B,1,T) in {0,1},
+ * label (B) or (1) int64 -> out (B,in,T). */
+int pt_refiner_forward(pt_model* m, const float* x, const float* condition, const float* mask, const int64_t* label,
+                       int n_label, int B, int T, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- glue kernels either side of the path -------------------------------------------------- */
+/* F.interpolate(pred, size=T_out, mode='linear') then gt*mask*mask' + pred*(1-mask)
+ * (predictor.py:445-446 with premask=1: first term (gt*mask)*mask; refiner.py:528-529,553 with premask=0: gt*mask).
+ * pred (B,C,T_in), gt (B,C,T_out), mask (B,1,T_out) -> out (B,C,T_out). gt/mask may be NULL (pure resize). */
+int pt_interp_blend(const float* pred, int B, int C, int T_in, int T_out, const float* gt, const float* mask,
+                    int premask, float* out, void* stream);
+
+/* ---- op-level entry points (unit tests, reuse) -------------------------------------------- */
+/* Conv1d / ConvTranspose1d on channels-last rows through the tap-GEMM: A [B*Lin, lda], W packed
+ * [k][Npad][Kpad], out [B*Lout, ldc].  kind: 0=k1 1=k3 2=k7 3=k4s2 4=convT k4s2. act: 0 none 1 leaky(slope) 2 gated. */
+int pt_conv1d_cl(const float* A, int lda, const float* Wpacked, const float* bias, int N, int Npad, int K, int kind,
+                 int B, int Lin, float* C, int ldc, int act, float slope, const float* Res, int ldr, void* stream);
+int pt_ncl_to_cl(const float* in, float* out, int B, int C, int L, int ldo, void* stream);
+int pt_cl_to_ncl(const float* in, int ldi, float* out, int B, int C, int L, void* stream);
+/* nearest-code search on channels-last rows: z [rows, ldz], codebooks [G][K][D] -> idx (rows,G), q [rows, ldq]. */
+int pt_pq_search_cl(const float* z, int ldz, const float* codebooks, int rows, int G, int D, int K, int64_t* idx,
+                    float* q, int ldq, void* stream);
+
+/* code gather on raw buffers: idx (rows,G) int32/int64, codebooks [G][K][D] -> out [rows, ldq] (quantize_all). */
+int pt_pq_gather_cl(const void* idx, int idx_are_int64, const float* codebooks, int rows, int G, int D, int K,
+                    float* out, int ldq, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,187 @@
+// extern "C" surface of libprobtalk_hip.so (declarations: include/probtalk_hip.h).
+#include <cstring>
+
+#include "../../include/probtalk_hip.h"
+#include "model.h"
+#include "transformer.h"
+
+using namespace pt;
+
+struct pt_model {
+  Model m;
+};
+
+extern "C" {
+
+const char* pt_last_error(void) { return last_error(); }
+int pt_version(void) { return 100; }
+
+pt_model* pt_model_create(const char* kind, const int* cfg, int ncfg) {
+  static const char* kinds[] = {"vqvae_sc", "vqvae_legacy", "cond_encoder", "predictor", "refiner"};
+  bool ok = false;
+  for (const char* k : kinds) ok = ok || (kind && strcmp(kind, k) == 0);
+  if (!ok) {
+    set_error("pt_model_create: unknown kind '%s'", kind ? kind : "(null)");
+    return nullptr;
+  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    set_error("pt_model_create: no HIP device available");
+    return nullptr;
+  }
+  pt_model* h = new pt_model();
+  h->m.kind = kind;
+  h->m.cfg.assign(cfg, cfg + ncfg);
+  return h;
+}
+
+int pt_model_set_tensor(pt_model* h, const char* name, const void* host_data, const int64_t* shape, int ndim,
+                        int dtype) {
+  PT_CHECK(h && name && host_data, "pt_model_set_tensor: null argument");
+  PT_CHECK(!h->m.finalized, "pt_model_set_tensor: model already finalized");
+  PT_CHECK(dtype == 0 || dtype == 1, "pt_model_set_tensor(%s): dtype %d unsupported (0=f32, 1=f64)", name, dtype);
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  t.dtype = dtype;
+  const int64_t n = t.numel();
+  PT_CHECK(n >= 0, "pt_model_set_tensor(%s): negative size", name);
+  if (dtype == 0) t.f.assign((const float*)host_data, (const float*)host_data + n);
+  else t.d.assign((const double*)host_data, (const double*)host_data + n);
+  h->m.sd[name] = std::move(t);
+  return 0;
+}
+
+int pt_model_finalize(pt_model* h) {
+  PT_CHECK(h, "pt_model_finalize: null model");
+  return finalize_model(h->m);
+}
+
+void pt_model_destroy(pt_model* h) { delete h; }
+
+// ---- PQ-VAE
+size_t pt_vqvae_workspace_bytes(const pt_model* h, int B, int T) {
+  if (!h || !h->m.finalized) return 0;
+  return vqvae_workspace_bytes(h->m, B, T);
+}
+int pt_vqvae_encode(pt_model* h, const float* x, int B, int T, float* z, float* quantized, int64_t* indices, void* ws,
+                    size_t ws_bytes, void* stream) {
+  PT_CHECK(h && x && indices, "pt_vqvae_encode: null argument");
+  return vqvae_encode(h->m, x, B, T, z, quantized, indices, ws, ws_bytes, (hipStream_t)stream);
+}
+int pt_vqvae_decode(pt_model* h, const float* e, int B, int Tq, float* out, void* ws, size_t ws_bytes, void* stream) {
+  PT_CHECK(h && e && out, "pt_vqvae_decode: null argument");
+  return vqvae_decode(h->m, e, nullptr, 0, B, Tq, out, ws, ws_bytes, (hipStream_t)stream);
+}
+int pt_vqvae_decode_codes(pt_model* h, const void* codes, int codes_are_int64, int B, int Tq, float* out, void* ws,
+                          size_t ws_bytes, void* stream) {
+  PT_CHECK(h && codes && out, "pt_vqvae_decode_codes: null argument");
+  return vqvae_decode(h->m, nullptr, codes, codes_are_int64, B, Tq, out, ws, ws_bytes, (hipStream_t)stream);
+}
+int pt_pq_quantize(pt_model* h, const float* z, int B, int W, float* quantized, int64_t* indices, void* ws,
+                   size_t ws_bytes, void* stream) {
+  PT_CHECK(h && z && indices, "pt_pq_quantize: null argument");
+  PT_CHECK(h->m.finalized && (h->m.kind == "vqvae_sc" || h->m.kind == "vqvae_legacy"), "pt_pq_quantize: wrong model");
+  PT_CHECK(B > 0 && W > 0, "pt_pq_quantize: empty input B=%d W=%d", B, W);
+  const VQVAE& v = h->m.vq;
+  hipStream_t s = (hipStream_t)stream;
+  Arena ar(ws, ws_bytes);
+  const int ld = ld_of(v.emb_dim);
+  float* z_cl = ar.f32((size_t)B * W * ld);
+  float* q_cl = ar.f32((size_t)B * W * ld);
+  PT_CHECK(!ar.overflow, "pt_pq_quantize: workspace too small (%zu given, %zu needed)", ws_bytes, ar.off);
+  if (launch_ncl_to_cl(z, z_cl, B, v.emb_dim, W, ld, 0, ld, s)) return 1;
+  if (launch_pq_search(z_cl, ld, v.codebooks, B * W, v.groups, v.emb_dim / v.groups, v.num_codes, indices,
+                       quantized ? q_cl : nullptr, ld, s)) return 1;
+  if (quantized && launch_cl_to_ncl(q_cl, ld, 0, quantized, B, v.emb_dim, W, s)) return 1;
+  return 0;
+}
+int pt_pq_quantize_all(pt_model* h, const void* idx, int idx_are_int64, int rows, float* out, void* stream) {
+  PT_CHECK(h && idx && out, "pt_pq_quantize_all: null argument");
+  PT_CHECK(h->m.finalized && (h->m.kind == "vqvae_sc" || h->m.kind == "vqvae_legacy"), "pt_pq_quantize_all: wrong model");
+  const VQVAE& v = h->m.vq;
+  return launch_pq_gather(idx, idx_are_int64, v.codebooks, rows, v.groups, v.emb_dim / v.groups, v.num_codes, out,
+                          v.emb_dim, v.emb_dim, (hipStream_t)stream);
+}
+
+// ---- audio condition encoder
+size_t pt_cond_encoder_workspace_bytes(const pt_model* h, int B, int T) {
+  if (!h || !h->m.finalized) return 0;
+  return cond_encoder_workspace_bytes(h->m, B, T);
+}
+int pt_cond_encoder_forward(pt_model* h, const float* aud, int B, int T, float* out, void* ws, size_t ws_bytes,
+                            void* stream) {
+  PT_CHECK(h && aud && out, "pt_cond_encoder_forward: null argument");
+  return cond_encoder_forward(h->m, aud, B, T, out, nullptr, 0, 0, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ---- predictor / refiner
+size_t pt_predictor_workspace_bytes(const pt_model* h, int B, int T) {
+  if (!h || !h->m.finalized) return 0;
+  return predictor_workspace_bytes(h->m, B, T);
+}
+int pt_predictor_condition(pt_model* h, const float* masked_motion, const float* mask, const float* audio, int B, int T,
+                           float* condition, void* ws, size_t ws_bytes, void* stream) {
+  PT_CHECK(h && masked_motion && mask && audio && condition, "pt_predictor_condition: null argument");
+  return predictor_condition(h->m, masked_motion, mask, audio, B, T, condition, ws, ws_bytes, (hipStream_t)stream);
+}
+int pt_predictor_logits(pt_model* h, const int32_t* ids, const int64_t* label, const float* condition, int B, int Tq,
+                        float* logits, void* ws, size_t ws_bytes, void* stream) {
+  PT_CHECK(h && ids && label && condition && logits, "pt_predictor_logits: null argument");
+  return predictor_logits(h->m, ids, label, condition, B, Tq, logits, ws, ws_bytes, (hipStream_t)stream);
+}
+int pt_predictor_sample(pt_model* h, const int64_t* label, const float* condition, const float* noise_q,
+                        const float* noise_g, int steps, int B, int Tq, int32_t* codes_out, float* logits_out, void* ws,
+                        size_t ws_bytes, void* stream) {
+  PT_CHECK(h && label && condition && noise_q && noise_g && codes_out, "pt_predictor_sample: null argument");
+  return predictor_sample(h->m, label, condition, noise_q, noise_g, steps, B, Tq, codes_out, logits_out, ws, ws_bytes,
+                          (hipStream_t)stream);
+}
+size_t pt_refiner_workspace_bytes(const pt_model* h, int B, int T) {
+  if (!h || !h->m.finalized) return 0;
+  return refiner_workspace_bytes(h->m, B, T);
+}
+int pt_refiner_forward(pt_model* h, const float* x, const float* condition, const float* mask, const int64_t* label,
+                       int n_label, int B, int T, float* out, void* ws, size_t ws_bytes, void* stream) {
+  PT_CHECK(h && x && condition && mask && label && out, "pt_refiner_forward: null argument");
+  return refiner_forward(h->m, x, condition, mask, label, n_label, B, T, out, ws, ws_bytes, (hipStream_t)stream);
+}
+int pt_interp_blend(const float* pred, int B, int C, int T_in, int T_out, const float* gt, const float* mask,
+                    int premask, float* out, void* stream) {
+  PT_CHECK(pred && out, "pt_interp_blend: null argument");
+  return launch_interp_blend(pred, B, C, T_in, T_out, gt, mask, premask, out, (hipStream_t)stream);
+}
+
+// ---- op level
+int pt_conv1d_cl(const float* A, int lda, const float* Wpacked, const float* bias, int N, int Npad, int K, int kind,
+                 int B, int Lin, float* C, int ldc, int act, float slope, const float* Res, int ldr, void* stream) {
+  PT_CHECK(A && Wpacked && C, "pt_conv1d_cl: null argument");
+  PT_CHECK(kind >= 0 && kind <= 4, "pt_conv1d_cl: kind %d out of range", kind);
+  DevConv c;
+  c.w = const_cast<float*>(Wpacked);
+  c.b = const_cast<float*>(bias);
+  c.N = N; c.Npad = Npad; c.K = K; c.Cin = K;
+  static const int slabs[] = {1, 3, 7, 4, 4};
+  c.slabs = slabs[kind];
+  return run_conv(c, (ConvKind)kind, A, lda, B, Lin, C, ldc, act, slope, Res, ldr, (hipStream_t)stream);
+}
+int pt_ncl_to_cl(const float* in, float* out, int B, int C, int L, int ldo, void* stream) {
+  PT_CHECK(in && out, "pt_ncl_to_cl: null argument");
+  return launch_ncl_to_cl(in, out, B, C, L, ldo, 0, ldo, (hipStream_t)stream);
+}
+int pt_cl_to_ncl(const float* in, int ldi, float* out, int B, int C, int L, void* stream) {
+  PT_CHECK(in && out, "pt_cl_to_ncl: null argument");
+  return launch_cl_to_ncl(in, ldi, 0, out, B, C, L, (hipStream_t)stream);
+}
+int pt_pq_search_cl(const float* z, int ldz, const float* codebooks, int rows, int G, int D, int K, int64_t* idx,
+                    float* q, int ldq, void* stream) {
+  PT_CHECK(z && codebooks && idx, "pt_pq_search_cl: null argument");
+  return launch_pq_search(z, ldz, codebooks, rows, G, D, K, idx, q, ldq, (hipStream_t)stream);
+}
+
+int pt_pq_gather_cl(const void* idx, int idx_are_int64, const float* codebooks, int rows, int G, int D, int K,
+                    float* out, int ldq, void* stream) {
+  PT_CHECK(idx && codebooks && out, "pt_pq_gather_cl: null argument");
+  return launch_pq_gather(idx, idx_are_int64, codebooks, rows, G, D, K, out, ldq, G * D, (hipStream_t)stream);
+}
+
+}  // extern "C"

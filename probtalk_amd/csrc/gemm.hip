@@ -1,0 +1,222 @@
+// tap-GEMM on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// One kernel covers every dense contraction on the ProbTalk path: Linear / 1x1 conv (1 tap), the
+// k3/k7 stride-1 and k4 stride-2 Conv1d blocks (taps = shifted row reads of the channels-last
+// activation) and the k4 stride-2 ConvTranspose1d (two 2-tap launches, one per output parity).
+// BatchNorm(eval) and the paired residual conv are folded into W/bias on the host (runtime.hip), so
+// the epilogue is bias (+fp64 PE) (+residual) + LeakyReLU/ReLU, or the tanh*sigmoid gate.
+//
+// Tiling: 256 threads = 4 waves in 2x2; each wave owns MI x NI tiles of 32x32 (16 accumulator
+// VGPRs each).  BK = 32 floats per stage, LDS rows padded to 36 floats (conflict-free ds_read_b128
+// fragment reads), double-buffered LDS with register prefetch of the next stage (one barrier/stage).
+// fp32 MFMA issues one 32x32x2 per 64 cycles per SIMD, so a stage of 16*MI*NI MFMAs per wave
+// (>= 1024 cycles) hides the 2*(MI+NI) dwordx4 global loads of the next stage.
+#include "pt_common.h"
+
+namespace pt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;
+constexpr int LDS_ST = BK + 4;  // floats per LDS row
+
+__device__ __forceinline__ float act_leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+template <int MI, int NI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p, const int tiles_n, const int nwg) {
+  constexpr int BM = 64 * MI, BN = 64 * NI;
+  constexpr int AI = 2 * MI, BI = 2 * NI;  // float4 loads per thread per stage
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int STAGE = (BM + BN) * LDS_ST;
+
+  // XCD-aware tile order: blocks b and b+8 share an L2, so give each XCD a contiguous run of tiles
+  // (n fastest) and let the A row-panel be re-read from that L2 (bijective form of the remap).
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c4 = tid & 7, r0 = tid >> 3;
+
+  // per-thread source rows of the A stage
+  int a_l[AI], a_rb[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    if (m < p.M) {
+      const int b = m / p.Lgrid;
+      a_l[i] = (m - b * p.Lgrid) * p.in_stride;
+      a_rb[i] = b * p.Lin;
+    } else {
+      a_l[i] = -(1 << 28);
+      a_rb[i] = 0;
+    }
+  }
+  const int kch = p.K / BK;
+  const int nk = p.ntaps * kch;
+
+  f32x4 ra[AI], rb[BI];
+  int tap = 0, kc = 0;
+  auto gload = [&]() {
+    const int d = p.tap_d[tap];
+    const float* Wt = p.W + (size_t)p.tap_w[tap] * p.Npad * p.K;
+    const int k = kc * BK + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int l = a_l[i] + d;
+      if ((unsigned)l < (unsigned)p.Lin)
+        ra[i] = *reinterpret_cast<const f32x4*>(p.A + (size_t)(a_rb[i] + l) * p.lda + k);
+      else
+        ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      rb[i] = *reinterpret_cast<const f32x4*>(Wt + (size_t)(n0 + r0 + 32 * i) * p.K + k);
+    if (++kc == kch) { kc = 0; ++tap; }
+  };
+  auto lstore = [&](int buf) {
+    float* As = smem + buf * STAGE;
+    float* Bs = As + BM * LDS_ST;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(As + (r0 + 32 * i) * LDS_ST + c4 * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(Bs + (r0 + 32 * i) * LDS_ST + c4 * 4) = rb[i];
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  gload();
+  lstore(0);
+  __syncthreads();
+
+  const int frag_off = (lane & 31) * LDS_ST + 4 * (lane >> 5);
+  for (int it = 0; it < nk; ++it) {
+    const bool more = it + 1 < nk;
+    if (more) gload();
+    const float* As = smem + (it & 1) * STAGE + (wm * 32 * MI) * LDS_ST + frag_off;
+    const float* Bs = smem + (it & 1) * STAGE + (BM + wn * 32 * NI) * LDS_ST + frag_off;
+#pragma unroll
+    for (int u = 0; u < BK / 8; ++u) {
+      f32x4 a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(As + mi * 32 * LDS_ST + u * 8);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(Bs + ni * 32 * LDS_ST + u * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+    }
+    if (more) lstore((it + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: D[i][j]: col j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool plain_rows = (p.out_stride == 1 && p.out_off == 0 && p.Lgrid == p.Lout);
+  const int lcol = lane & 31, lrow = 4 * (lane >> 5);
+  const bool gated = (p.act == ACT_GATED);
+  const int n_out = gated ? p.N / 2 : p.N;
+
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + lrow;
+      if (m >= p.M) continue;
+      int orow = m;
+      if (!plain_rows) {
+        const int b = m / p.Lgrid;
+        orow = b * p.Lout + (m - b * p.Lgrid) * p.out_stride + p.out_off;
+      }
+      float* crow = p.C + (size_t)orow * p.ldc;
+      if (gated) {
+        if constexpr (NI % 2 == 0) {
+#pragma unroll
+          for (int pr = 0; pr < NI / 2; ++pr) {
+            const int nperm = n0 + wn * 32 * NI + pr * 64 + lcol;  // 'a' row; 'b' row is +32
+            const int col = (n0 + wn * 32 * NI + pr * 64) / 2 + lcol;
+            if (col < n_out) {
+              float va = acc[mi][2 * pr][r], vb = acc[mi][2 * pr + 1][r];
+              if (p.bias) { va += p.bias[nperm]; vb += p.bias[nperm + 32]; }
+              const float g = tanhf(va) * (1.f / (1.f + expf(-vb)));
+              crow[col] = g;
+            } else if (col < p.zero_to) {
+              crow[col] = 0.f;
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int col = n0 + wn * 32 * NI + ni * 32 + lcol;
+          if (col < n_out) {
+            float v = acc[mi][ni][r];
+            if (p.bias) v += p.bias[col];
+            if (p.pe) v = (float)((double)v + p.pe[(size_t)(orow % p.pe_period) * p.N + col]);
+            if (p.Res) v += p.Res[(size_t)orow * p.ldr + col];
+            if (p.act == ACT_LEAKY) v = act_leaky(v, p.slope);
+            crow[col] = v;
+          } else if (col < p.zero_to) {
+            crow[col] = 0.f;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int MI, int NI>
+static int launch_cfg(const GemmArgs& a, hipStream_t s) {
+  constexpr int BM = 64 * MI, BN = 64 * NI;
+  constexpr size_t smem = 2 * (size_t)(BM + BN) * LDS_ST * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<MI, NI>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_set = true;
+  }
+  const int tiles_m = (a.M + BM - 1) / BM;
+  const int tiles_n = (a.N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  hipLaunchKernelGGL((gemm_f32_kernel<MI, NI>), dim3(nwg), dim3(256), smem, s, a, tiles_n, nwg);
+  PT_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gemm(const GemmArgs& a, hipStream_t s) {
+  PT_CHECK(a.M > 0 && a.N > 0, "gemm: empty problem M=%d N=%d", a.M, a.N);
+  PT_CHECK(a.K % BK == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of %d", a.K, BK);
+  PT_CHECK(a.lda >= a.K && a.lda % 4 == 0, "gemm: lda=%d must be >= K=%d and a multiple of 4", a.lda, a.K);
+  PT_CHECK(a.Npad % 128 == 0 && a.Npad >= a.N, "gemm: Npad=%d must be a multiple of 128 and >= N=%d", a.Npad, a.N);
+  PT_CHECK(a.ntaps >= 1 && a.ntaps <= MAX_TAPS, "gemm: ntaps=%d out of range", a.ntaps);
+  PT_CHECK(a.Lgrid > 0 && a.M % a.Lgrid == 0, "gemm: M=%d is not a multiple of Lgrid=%d", a.M, a.Lgrid);
+  PT_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm: A and W must be 16-byte aligned");
+  const int n_out = a.act == ACT_GATED ? a.N / 2 : a.N;
+  PT_CHECK(a.ldc >= n_out && a.zero_to <= a.ldc, "gemm: ldc=%d too small for N=%d / zero_to=%d", a.ldc, n_out, a.zero_to);
+  if (a.act == ACT_GATED) {
+    PT_CHECK(a.N % 64 == 0, "gemm: gated N=%d must be a multiple of 64", a.N);
+    PT_CHECK(a.pe == nullptr && a.Res == nullptr, "gemm: gated epilogue takes no pe/residual");
+  }
+  auto tiles = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+  // Prefer the largest tile that still gives every CU >= 2 workgroups (256 CUs).
+  if (tiles(128, 128) >= 512) return launch_cfg<2, 2>(a, s);
+  if (tiles(64, 128) >= 384 || a.act == ACT_GATED) return launch_cfg<1, 2>(a, s);
+  return launch_cfg<1, 1>(a, s);
+}
+
+}  // namespace pt

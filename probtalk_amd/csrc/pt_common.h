@@ -1,0 +1,71 @@
+// Shared declarations for the ProbTalk MI355X (gfx950) hot-path library.
+// Internal header: the public C-ABI is include/probtalk_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace pt {
+
+// Activation layout inside the library: channels-last, [B*L, ld] fp32 rows with
+// ld = round_up(C, 32) and columns C..ld-1 kept at zero, so every GEMM runs
+// without K-tail guards.
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline int ld_of(int C) { return round_up(C, 32); }
+
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+#define PT_CHECK(cond, ...)                                   \
+  do {                                                        \
+    if (!(cond)) {                                            \
+      ::pt::set_error(__VA_ARGS__);                           \
+      return 1;                                               \
+    }                                                         \
+  } while (0)
+
+#define PT_HIP(expr)                                                             \
+  do {                                                                           \
+    hipError_t e_ = (expr);                                                      \
+    if (e_ != hipSuccess) {                                                      \
+      ::pt::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return 1;                                                                  \
+    }                                                                            \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// tap-GEMM: C[orow(m), n] = act( sum_t sum_k A[src(m,t), k] * W[t][n][k] + bias[n] (+pe) (+Res) )
+// Covers Linear, 1x1 conv, k3/k7 s1 conv, k4 s2 conv and (per output parity) k4 s2 ConvTranspose.
+// ---------------------------------------------------------------------------
+enum Act { ACT_NONE = 0, ACT_LEAKY = 1, ACT_GATED = 2 };
+constexpr int MAX_TAPS = 8;
+
+struct GemmArgs {
+  const float* A;   int lda;     // [B*Lin, lda]
+  const float* W;                // [slabs][Npad][K]
+  const float* bias;             // [N] (gated: [N] in permuted order) or nullptr
+  const float* Res; int ldr;     // residual, indexed by OUTPUT row, or nullptr
+  float* C;         int ldc;     // output rows of ldc floats
+  const double* pe; int pe_period;  // optional fp64 table [pe_period][N]; added in fp64 then rounded (PTransformer.py:679-683)
+  int M, N, K, Npad;             // M = B*Lgrid GEMM rows; N real out channels (gated: 2*out); K multiple of 32
+  int ntaps;
+  int tap_d[MAX_TAPS];           // source frame offset per tap
+  int tap_w[MAX_TAPS];           // weight slab per tap
+  int Lgrid, Lin, Lout;          // rows per clip: GEMM grid / source / destination
+  int in_stride, out_stride, out_off;
+  int act; float slope;
+  int zero_to;                   // columns [Nout, zero_to) of C are written as zeros
+};
+int launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// layout
+int launch_ncl_to_cl(const float* in, float* out, int B, int C, int L, int ldo, int col_off, int zero_to, hipStream_t s);
+int launch_cl_to_ncl(const float* in, int ldi, int col_off, float* out, int B, int C, int L, hipStream_t s);
+
+// product quantizer
+int launch_pq_search(const float* z_cl, int ldz, const float* codebooks, int rows, int G, int D, int K,
+                     int64_t* idx, float* q_cl, int ldq, hipStream_t s);
+int launch_pq_gather(const void* idx, int idx_is_i64, const float* codebooks, int rows, int G, int D, int K,
+                     float* q_cl, int ldq, int zero_to, hipStream_t s);
+
+}  // namespace pt

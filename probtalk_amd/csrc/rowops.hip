@@ -1,0 +1,282 @@
+// Row-wise (HBM-bound) kernels of the predictor / refiner transformers: token embedding + fp64
+// positional encodings, the identity-conditioned "stylization" pre-op (LayerNorm -> (1+scale),shift
+// -> SiLU), post-LN residual, the MaskGIT re-masking step and linear resize + mask blend.
+// d_model is 512 on this path: one 64-lane wave owns one row = 8 floats per lane (2 x dwordx4).
+#include "transformer.h"
+
+namespace pt {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int DM = 512;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+struct Row8 {
+  f32x4 a, b;
+};
+__device__ __forceinline__ Row8 load_row(const float* p, int lane) {
+  Row8 r;
+  r.a = *reinterpret_cast<const f32x4*>(p + lane * 4);
+  r.b = *reinterpret_cast<const f32x4*>(p + 256 + lane * 4);
+  return r;
+}
+__device__ __forceinline__ void store_row(float* p, int lane, const Row8& r) {
+  *reinterpret_cast<f32x4*>(p + lane * 4) = r.a;
+  *reinterpret_cast<f32x4*>(p + 256 + lane * 4) = r.b;
+}
+// LayerNorm statistics of one 512-wide row held across the wave (two-pass, biased variance, eps 1e-5)
+__device__ __forceinline__ void ln_stats(const Row8& r, float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s += r.a[i] + r.b[i];
+  mean = wave_sum(s) * (1.f / DM);
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float da = r.a[i] - mean, db = r.b[i] - mean;
+    v += da * da + db * db;
+  }
+  rstd = 1.0f / sqrtf(wave_sum(v) * (1.f / DM) + 1e-5f);
+}
+
+// x[row] = float(double(tok_emb[id]) + (PE[t+1] + PPE[g+1]))   (PTransformer.py:659-679)
+__global__ __launch_bounds__(256) void embed_pe_kernel(const int* __restrict__ ids, const float* __restrict__ tok,
+                                                       const double* __restrict__ pe, const double* __restrict__ ppe,
+                                                       float* __restrict__ x, int rows, int N, int G, int vocab) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int n = row % N, t = n / G, g = n - t * G;
+  int id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float* e = tok + (size_t)id * DM;
+  const double* p1 = pe + (size_t)(t + 1) * DM;
+  const double* p2 = ppe + (size_t)(g + 1) * DM;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int c = half * 256 + lane * 4;
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (float)((double)e[c + i] + (p1[c + i] + p2[c + i]));
+    *reinterpret_cast<f32x4*>(x + (size_t)row * DM + c) = o;
+  }
+}
+int launch_embed_pe(const int* ids, const float* tok, const double* pe, const double* ppe, float* x, int rows, int N,
+                    int G, int vocab, hipStream_t s) {
+  hipLaunchKernelGGL(embed_pe_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, ids, tok, pe, ppe, x, rows, N, G, vocab);
+  PT_HIP(hipGetLastError());
+  return 0;
+}
+
+// out = SiLU(LN(h; g, b) * (1 + scale[label]) + shift[label])     (PTransformer.py:134-139)
+// style: [n_classes][2*DM] = emb_layers_2(SiLU(class_embed[c])) precomputed at load; label per clip.
+__global__ __launch_bounds__(256) void ln_mod_silu_kernel(const float* __restrict__ h, float* __restrict__ out,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ style,
+                                                          const int64_t* __restrict__ label, int n_label, int rows,
+                                                          int rows_per_clip, int n_classes) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  Row8 r = load_row(h + (size_t)row * DM, lane);
+  float mean, rstd;
+  ln_stats(r, mean, rstd);
+  const int clip = row / rows_per_clip;
+  long long lb = label[n_label == 1 ? 0 : clip];
+  lb = lb < 0 ? 0 : (lb >= n_classes ? n_classes - 1 : lb);
+  const float* st = style + (size_t)lb * 2 * DM;
+  const Row8 g = load_row(gamma, lane), b = load_row(beta, lane), sc = load_row(st, lane), sh = load_row(st + DM, lane);
+  Row8 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float ya = ((r.a[i] - mean) * rstd * g.a[i] + b.a[i]) * (1.f + sc.a[i]) + sh.a[i];
+    float yb = ((r.b[i] - mean) * rstd * g.b[i] + b.b[i]) * (1.f + sc.b[i]) + sh.b[i];
+    o.a[i] = ya / (1.f + expf(-ya));
+    o.b[i] = yb / (1.f + expf(-yb));
+  }
+  store_row(out + (size_t)row * DM, lane, o);
+}
+int launch_ln_mod_silu(const float* h, float* out, const float* gamma, const float* beta, const float* style,
+                       const int64_t* label, int n_label, int rows, int rows_per_clip, int n_classes, hipStream_t s) {
+  hipLaunchKernelGGL(ln_mod_silu_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, h, out, gamma, beta, style, label,
+                     n_label, rows, rows_per_clip, n_classes);
+  PT_HIP(hipGetLastError());
+  return 0;
+}
+
+// x = LN(x + y; g, b)   (post-LN residual, PTransformer.py:329-331)
+__global__ __launch_bounds__(256) void add_ln_kernel(float* __restrict__ x, const float* __restrict__ y,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     int rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  Row8 r = load_row(x + (size_t)row * DM, lane);
+  const Row8 t = load_row(y + (size_t)row * DM, lane);
+  r.a += t.a;
+  r.b += t.b;
+  float mean, rstd;
+  ln_stats(r, mean, rstd);
+  const Row8 g = load_row(gamma, lane), b = load_row(beta, lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r.a[i] = (r.a[i] - mean) * rstd * g.a[i] + b.a[i];
+    r.b[i] = (r.b[i] - mean) * rstd * g.b[i] + b.b[i];
+  }
+  store_row(x + (size_t)row * DM, lane, r);
+}
+int launch_add_ln(float* x, const float* y, const float* gamma, const float* beta, int rows, hipStream_t s) {
+  hipLaunchKernelGGL(add_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, y, gamma, beta, rows);
+  PT_HIP(hipGetLastError());
+  return 0;
+}
+
+// refiner condition: one-hot(mask) appended as two channels (RTransformer.py:218-219):
+// cond_cl[row][C0] = (mask==0), cond_cl[row][C0+1] = (mask==1), remaining pad columns zero.
+__global__ void mask_onehot_kernel(const float* __restrict__ mask, float* __restrict__ cond, int rows, int ld, int c0,
+                                   int zero_to) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const long long m = (long long)mask[row];
+  float* p = cond + (size_t)row * ld;
+  p[c0] = m == 0 ? 1.f : 0.f;
+  p[c0 + 1] = m == 1 ? 1.f : 0.f;
+  for (int c = c0 + 2; c < zero_to; ++c) p[c] = 0.f;
+}
+int launch_mask_onehot(const float* mask, float* cond, int rows, int ld, int c0, int zero_to, hipStream_t s) {
+  hipLaunchKernelGGL(mask_onehot_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, mask, cond, rows, ld, c0, zero_to);
+  PT_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// One MaskGIT iteration after the logits call (PTransformer.py:607-638), one workgroup per clip:
+//   sampled = argmax(softmax(logits) / q)            (torch.multinomial's single-draw path)
+//   conf    = log p[sampled] + temp * gumbel, +inf for tokens already known
+//   re-mask every token whose confidence is below the mask_len-th smallest.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maskgit_step_kernel(const float* __restrict__ logits,
+                                                           const float* __restrict__ noise_q,
+                                                           const float* __restrict__ noise_g, int* __restrict__ ids,
+                                                           int N, int V, int mask_id, int want_mask, float temp) {
+  extern __shared__ float sm[];
+  float* conf = sm;                                  // [N]
+  int* samp = reinterpret_cast<int*>(conf + N);      // [N]
+  __shared__ int unknown_cnt;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) unknown_cnt = 0;
+  __syncthreads();
+  int my_unknown = 0;
+  for (int n = wave; n < N; n += 4) {
+    const float* lg = logits + ((size_t)b * N + n) * V;
+    const float* q = noise_q + ((size_t)b * N + n) * V;
+    float mx = -INFINITY;
+    for (int c = lane; c < V; c += 64) mx = fmaxf(mx, lg[c]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < V; c += 64) sum += expf(lg[c] - mx);
+    sum = wave_sum(sum);
+    float best = -INFINITY, bestp = 0.f;
+    int besti = 0x7fffffff;
+    for (int c = lane; c < V; c += 64) {
+      const float p = expf(lg[c] - mx) / sum;
+      const float r = p / q[c];
+      if (r > best) { best = r; besti = c; bestp = p; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const float ob = __shfl_xor(best, o), op = __shfl_xor(bestp, o);
+      const int oi = __shfl_xor(besti, o);
+      if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; bestp = op; }
+    }
+    if (lane == 0) {
+      const int cur = ids[(size_t)b * N + n];
+      const bool unk = cur == mask_id;
+      samp[n] = unk ? besti : cur;
+      conf[n] = unk ? logf(bestp) + temp * noise_g[(size_t)b * N + n] : INFINITY;
+      my_unknown += unk;
+    }
+  }
+  if (lane == 0 && my_unknown) atomicAdd(&unknown_cnt, my_unknown);
+  __syncthreads();
+  int k = unknown_cnt - 1;
+  k = k < want_mask ? k : want_mask;
+  k = k < 0 ? 0 : k;
+  for (int n = tid; n < N; n += 256) {
+    const float c = conf[n];
+    int le = 0;
+    for (int m = 0; m < N; ++m) le += conf[m] <= c;
+    ids[(size_t)b * N + n] = (le <= k) ? mask_id : samp[n];
+  }
+}
+int launch_maskgit_step(const float* logits, const float* noise_q, const float* noise_g, int* ids, int B, int N, int V,
+                        int mask_id, int want_mask, float temp, hipStream_t s) {
+  PT_CHECK(N > 0 && N <= 8192, "maskgit_step: N=%d out of range", N);
+  hipLaunchKernelGGL(maskgit_step_kernel, dim3(B), dim3(256), (size_t)N * 8, s, logits, noise_q, noise_g, ids, N, V,
+                     mask_id, want_mask, temp);
+  PT_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void fill_i32_kernel(int* p, int v, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+int launch_fill_i32(int* p, int v, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
+  PT_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// F.interpolate(mode='linear', align_corners=False) along time + mask blend, NCL in / NCL out.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void interp_blend_kernel(const float* __restrict__ pred, int T_in, int T_out,
+                                                           const float* __restrict__ gt,
+                                                           const float* __restrict__ mask, int premask,
+                                                           float* __restrict__ out, int C, size_t total) {
+  const float scale = (float)T_in / (float)T_out;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int t = (int)(e % T_out);
+    const size_t bc = e / T_out;
+    float v;
+    if (T_in == T_out) {
+      v = pred[bc * T_in + t];
+    } else {
+      float src = scale * ((float)t + 0.5f) - 0.5f;
+      src = src < 0.f ? 0.f : src;
+      const int i0 = (int)src;
+      const int i1 = i0 + (i0 < T_in - 1 ? 1 : 0);
+      const float l1 = src - (float)i0, l0 = 1.f - l1;
+      v = l0 * pred[bc * T_in + i0] + l1 * pred[bc * T_in + i1];
+    }
+    if (gt) {
+      const float m = mask[(bc / C) * T_out + t];
+      float a = gt[e] * m;
+      if (premask) a = a * m;
+      v = a + v * (1.f - m);
+    }
+    out[e] = v;
+  }
+}
+int launch_interp_blend(const float* pred, int B, int C, int T_in, int T_out, const float* gt, const float* mask,
+                        int premask, float* out, hipStream_t s) {
+  PT_CHECK(B > 0 && C > 0 && T_in > 0 && T_out > 0, "interp_blend: empty tensor");
+  PT_CHECK((gt == nullptr) == (mask == nullptr), "interp_blend: gt and mask go together");
+  const size_t total = (size_t)B * C * T_out;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(interp_blend_kernel, dim3(blocks), dim3(256), 0, s, pred, T_in, T_out, gt, mask, premask, out, C,
+                     total);
+  PT_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace pt
