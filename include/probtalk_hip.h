@@ -107,6 +107,10 @@ int pt_cl_to_ncl(const float* in, int ldi, float* out, int B, int C, int L, void
 int pt_pq_search_cl(const float* z, int ldz, const float* codebooks, int rows, int G, int D, int K, int64_t* idx,
                     float* q, int ldq, void* stream);
 
+/* softmax(Q K^T / 8) V per (clip, head), head dim 64 (nn.MultiheadAttention core, PTransformer.py:340-353):
+ * Q rows b*Nq+i at Q + row*ldq + head*64; K/V rows b*Nk+j likewise; O like Q. */
+int pt_attention_cl(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,
+                    int Nq, int Nk, int H, void* stream);
 /* code gather on raw buffers: idx (rows,G) int32/int64, codebooks [G][K][D] -> out [rows, ldq] (quantize_all). */
 int pt_pq_gather_cl(const void* idx, int idx_are_int64, const float* codebooks, int rows, int G, int D, int K,
                     float* out, int ldq, void* stream);

@@ -178,6 +178,11 @@ int pt_pq_search_cl(const float* z, int ldz, const float* codebooks, int rows, i
   return launch_pq_search(z, ldz, codebooks, rows, G, D, K, idx, q, ldq, (hipStream_t)stream);
 }
 
+int pt_attention_cl(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,
+                    int Nq, int Nk, int H, void* stream) {
+  PT_CHECK(Q && K && V && O, "pt_attention_cl: null argument");
+  return launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, Nq, Nk, H, (hipStream_t)stream);
+}
 int pt_pq_gather_cl(const void* idx, int idx_are_int64, const float* codebooks, int rows, int G, int D, int K,
                     float* out, int ldq, void* stream) {
   PT_CHECK(idx && codebooks && out, "pt_pq_gather_cl: null argument");

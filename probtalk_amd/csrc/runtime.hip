@@ -20,7 +20,10 @@ void set_error(const char* fmt, ...) {
 }
 const char* last_error() { return g_err; }
 
+void free_transformer_models(Model& m);  // transformer.hip
+
 Model::~Model() {
+  free_transformer_models(*this);
   for (void* p : allocs) (void)hipFree(p);
 }
 
@@ -100,6 +103,11 @@ static int pack_conv(Model& m, DevConv& out, const std::string& w1, const std::s
   }
   if (upload(m, hw, &out.w)) return 1;
   return upload(m, hb, &out.b);
+}
+
+int pack_conv_public(Model& m, DevConv& out, const std::string& w1, const std::string& bn, const std::string& w2,
+                     bool transposed, bool gated) {
+  return pack_conv(m, out, w1, bn, w2, transposed, gated);
 }
 
 static int pack_stack(Model& m, ResStack& st, const std::string& p) {

@@ -16,6 +16,8 @@ int predictor_sample(Model& m, const int64_t* label, const float* condition, con
 size_t refiner_workspace_bytes(const Model& m, int B, int T);
 int refiner_forward(Model& m, const float* x, const float* condition, const float* mask, const int64_t* label,
                     int n_label, int B, int T, float* out, void* ws, size_t ws_bytes, hipStream_t s);
+int launch_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                     int B, int Nq, int Nk, int H, hipStream_t s);
 int launch_interp_blend(const float* pred, int B, int C, int T_in, int T_out, const float* gt, const float* mask,
                         int premask, float* out, hipStream_t s);
 

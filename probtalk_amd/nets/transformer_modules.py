@@ -1,0 +1,324 @@
+"""nn.Module mirror of the predictor / refiner networks on libprobtalk_hip.so.
+
+Reference classes mirrored (relative to /root/reference):
+  nets/inpainting/gated_pixelcnn_1d.py:39-83     GatedConv
+  nets/inpainting/predictornet.py:13-112         PredictorNet
+  nets/inpainting/PTransformer.py:28-165         StylizationBlock_V3 (type 'sb')
+  nets/inpainting/PTransformer.py:214-268        PositionalEncoding
+  nets/inpainting/PTransformer.py:284-372        DeepSupervisionLayer
+  nets/inpainting/PTransformer.py:394-704        PTransformer (tokens_to_logits, sample_good)
+  nets/inpainting/RTransformer.py:181-230        RTransformer
+The torch sub-modules are parameter containers (same state_dict keys as the reference); compute
+goes through the C ABI.  Eval mode only in this round.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.init import xavier_uniform_
+
+from .. import _lib
+from .._lib import check, ptr, stream
+from .modules import _HandleOwner, _cuda_f32, _train_guard
+
+
+def zero_module(module):
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+class StylizationBlock_V3(nn.Module):
+    def __init__(self, type, in_dim, groups, dropout=0.1):
+        super().__init__()
+        if list(type) != ['sb']:
+            raise NotImplementedError("only style_type=['sb'] is on the configured path (PTransformer.py:430)")
+        self.type = type
+        self.emb_layers_2 = nn.Sequential(nn.SiLU(), nn.Linear(in_dim, in_dim * 2))
+        self.norm_2 = nn.LayerNorm(in_dim)
+        self.out_layers_2 = nn.Sequential(nn.SiLU(), nn.Dropout(p=dropout), zero_module(nn.Linear(in_dim, in_dim)))
+
+
+class PositionalEncoding(nn.Module):
+    """Sinusoid table with a zero PAD row 0, kept in float64 like the reference (PTransformer.py:227-245)."""
+
+    def __init__(self, d_model, max_seq_len, sine=True):
+        super().__init__()
+        self.position_encoding = nn.Embedding(max_seq_len + 1, d_model)
+        if sine:
+            pe = np.array([[pos / np.power(10000, 2.0 * (j // 2) / d_model) for j in range(d_model)]
+                           for pos in range(max_seq_len)])
+            pe[:, 0::2] = np.sin(pe[:, 0::2])
+            pe[:, 1::2] = np.cos(pe[:, 1::2])
+            table = torch.cat((torch.zeros([1, d_model]), torch.from_numpy(pe)))
+            self.position_encoding.weight = nn.Parameter(table, requires_grad=False)
+        else:
+            self.position_encoding.weight = nn.Parameter(torch.zeros(max_seq_len + 1, d_model), requires_grad=True)
+
+
+class DeepSupervisionLayer(nn.TransformerDecoderLayer):
+    def __init__(self, d_model, nhead, groups, sb_every_layer=True, dropout=0.1, maskgit=False, style_type=['sb']):
+        super().__init__(d_model, nhead, dropout=dropout)
+        if not sb_every_layer:
+            raise NotImplementedError("identity=False (no style blocks) is not on the configured path")
+        self.d_model = d_model
+        self.groups = groups
+        self.sb_every_layer = sb_every_layer
+        self.maskgit = maskgit
+        self.style_type = style_type
+        self.style_gourp_1 = StylizationBlock_V3(style_type, d_model, groups, dropout=0.)
+        self.style_gourp_2 = StylizationBlock_V3(style_type, d_model, groups, dropout=0.)
+        self.style_gourp_3 = StylizationBlock_V3(style_type, d_model, groups, dropout=0.)
+        if groups > 1:
+            self.pad_1 = nn.Parameter(torch.zeros([1, d_model, groups - 1]))
+            self.pad_2 = nn.Parameter(torch.zeros([1, d_model, groups - 1]))
+            self.pad_3 = nn.Parameter(torch.zeros([1, d_model, groups - 1]))
+            xavier_uniform_(self.pad_1)
+            xavier_uniform_(self.pad_2)
+            xavier_uniform_(self.pad_3)
+        else:
+            self.pad_1 = self.pad_2 = self.pad_3 = 0
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("DeepSupervisionLayer is fused into its parent module's HIP sequence")
+
+
+class GatedConv(nn.Module):
+    def __init__(self, dim, kernel, stride, padding, residual, upsample=False, double=False):
+        super().__init__()
+        assert residual and not upsample and not double
+        self.residual = residual
+        self.in_dim = dim // 2 if (stride == 2 and dim > 128) else dim
+        self.vert_stack = nn.Conv1d(self.in_dim, dim * 2, kernel, stride, padding)
+        self.conv = nn.Conv1d(self.in_dim, dim, kernel, stride, padding) if stride == 2 else nn.Identity()
+        self.res = nn.Conv1d(dim, dim, 1)
+
+
+class PTransformer(nn.Module):
+    """MaskGIT token transformer.  Owns no handle: it computes through its PredictorNet parent
+    (set by PredictorNet.__init__), because the packed model also holds the motion-context encoder."""
+
+    def __init__(self, groups=4, input_dim=512, condi_dim=256, intermediate_dim=512, num_hidden_layers=12,
+                 num_code=512, n_classes=4, identity=False, maskgit=False):
+        super().__init__()
+        if not maskgit or not identity:
+            raise NotImplementedError("only the maskgit=True, identity=True form is on the configured path")
+        if intermediate_dim != 512:
+            raise NotImplementedError("d_model must be 512")
+        self.groups = groups
+        self.num_code = num_code
+        self.mask_id = num_code
+        self.identity = identity
+        self.maskgit = maskgit
+        self.choice_temperature = 4.5
+        self.tp_pe = True
+        self.n_classes = n_classes
+        self.num_hidden_layers = num_hidden_layers
+        self.condi_dim = condi_dim
+        try:
+            sine = bool(int(os.environ['sine']))
+        except Exception:
+            sine = True
+        self.tok_emb = nn.Embedding(num_code + 1, intermediate_dim)
+        self.class_embed = nn.Embedding(n_classes, intermediate_dim)
+        self.condi_emb = nn.Conv1d(condi_dim, intermediate_dim, 1)
+        self.PE = PositionalEncoding(intermediate_dim, 1800, sine=sine)
+        self.product_PE = PositionalEncoding(intermediate_dim, groups, sine=sine)
+        layer = DeepSupervisionLayer(d_model=intermediate_dim, nhead=8, groups=groups, sb_every_layer=identity,
+                                     dropout=0.1, maskgit=maskgit, style_type=['sb'])
+        self.transformer_decoder = nn.TransformerDecoder(layer, num_layers=num_hidden_layers)
+        self.output_conv = nn.Sequential(nn.Conv1d(intermediate_dim, 512, 1), nn.ReLU(True), nn.Conv1d(512, num_code, 1))
+        self.epoch_ratio = 0
+
+    def _owner(self):
+        o = self.__dict__.get("_pt_owner")
+        if o is None:
+            raise RuntimeError("PTransformer computes through its PredictorNet (construct it via PredictorNet)")
+        return o
+
+    def tokens_to_logits(self, x, label, condition):
+        """x (B,T',G) int (mask id = num_code), label (B,), condition (B,768,T') -> (B,T',G,num_code)."""
+        _train_guard(self, "PTransformer.tokens_to_logits")
+        cond = _cuda_f32(condition)
+        B, _, Tq = cond.shape
+        ids = x.to(device=cond.device, dtype=torch.int32).contiguous()
+        lab = label.to(device=cond.device, dtype=torch.int64).contiguous()
+        if lab.numel() != B:
+            raise RuntimeError(f"label must hold one speaker id per clip ({B}), got {lab.numel()}")
+        h = self._owner()._handle()
+        L = _lib.lib()
+        logits = torch.empty(B, Tq, self.groups, self.num_code, device=cond.device)
+        ws = h.workspace(L.pt_predictor_workspace_bytes(h.h, B, Tq * 8))
+        check(L.pt_predictor_logits(h.h, ptr(ids), ptr(lab), ptr(cond), B, Tq, ptr(logits), ptr(ws), ws.numel(),
+                                    stream()))
+        return logits
+
+    @torch.no_grad()
+    def sample_good(self, label=None, condition=None, input_codes=None, T=10, mode="cosine", noise=None,
+                    return_logits=False):
+        """MaskGIT decoding (PTransformer.py:590-642) -> codes (B,T',G) int32.
+
+        `noise=(q, g)` injects the two random draws (q ~ Exp(1) of shape (T,B,N,num_code) for the
+        categorical sample, g ~ Gumbel(0,1) of shape (T,B,N)); by default they are drawn on the
+        GPU (the reference draws the Gumbel noise on the CPU and copies it each pass)."""
+        _train_guard(self, "PTransformer.sample_good")
+        if mode != "cosine":
+            raise NotImplementedError("sample_good is only called with the cosine schedule")
+        cond = _cuda_f32(condition)
+        B, _, Tq = cond.shape
+        N = Tq * self.groups
+        lab = label.to(device=cond.device, dtype=torch.int64).contiguous()
+        if noise is None:
+            q = torch.empty(T, B, N, self.num_code, device=cond.device).exponential_(1.0)
+            u = torch.rand(T, B, N, device=cond.device).clamp_(1e-20, 1.0 - 1e-7)
+            g = -torch.log(-torch.log(u))
+        else:
+            q, g = (_cuda_f32(t) for t in noise)
+            if tuple(q.shape) != (T, B, N, self.num_code) or tuple(g.shape) != (T, B, N):
+                raise RuntimeError("sample_good: injected noise has the wrong shape")
+        h = self._owner()._handle()
+        L = _lib.lib()
+        codes = torch.empty(B, Tq, self.groups, dtype=torch.int32, device=cond.device)
+        logits = torch.empty(T, B, N, self.num_code, device=cond.device) if return_logits else None
+        ws = h.workspace(L.pt_predictor_workspace_bytes(h.h, B, Tq * 8))
+        check(L.pt_predictor_sample(h.h, ptr(lab), ptr(cond), ptr(q), ptr(g), T, B, Tq, ptr(codes), ptr(logits),
+                                    ptr(ws), ws.numel(), stream()))
+        return (codes, logits) if return_logits else codes
+
+    def forward(self, x, label, condition, input_codes, epoch_ratio):
+        raise NotImplementedError("PTransformer.forward is the training path (not built yet)")
+
+
+class PredictorNet(_HandleOwner, nn.Module):
+    """predictornet.py:13-112."""
+    _kind = "predictor"
+
+    def __init__(self, knn=False, mot_dim=256, sta_dim=2048, dim=64, enc_layers=10, ar_layers=15, n_classes=10,
+                 groups=1, identity=False, maskgit=False, maskgit_T=8, transformer=False, text=False, audio=True,
+                 motion_context=True):
+        super().__init__()
+        if not transformer:
+            raise NotImplementedError("the PixelCNN decoder (transformer=False) is not on the configured path")
+        if not motion_context or text is not None or audio is None or knn:
+            raise NotImplementedError("only motion_context=True, audio set, text=None, knn=False is on the configured path")
+        if dim != 512 or enc_layers != 10:
+            raise NotImplementedError("the HIP sequence is built for dim=512, enc_layers=10 (predictor.py:72)")
+        self.dim = dim
+        self.knn = knn
+        self.groups = groups
+        self.ar_layers = ar_layers
+        self.num_code = sta_dim
+        self.mask_id = self.num_code
+        self.maskgit = maskgit
+        self.T = maskgit_T
+        self.motion_context = motion_context
+        self.is_transformer = transformer
+        self.mot_dim = mot_dim
+        self.n_classes = n_classes
+        self.motion_embedding = nn.Conv1d(mot_dim + 1, dim // 4, 1, 1, padding=0)
+        self.enc = nn.ModuleList()
+        d = dim // 4
+        for i in range(enc_layers):
+            if i == 0:
+                kernel, stride, padding = 7, 1, 3
+            elif i in [2, 4, 6]:
+                kernel, stride, padding = 4, 2, 1
+                if i in [4, 6]:
+                    d = d * 2
+            else:
+                kernel, stride, padding = 3, 1, 1
+            self.enc.append(GatedConv(d, kernel, stride, padding, True))
+        condi_dim = d + 256 * (audio is not None) + 256 * (text is not None)
+        self.decoder = PTransformer(groups, 512, condi_dim, 512, 6, self.num_code, n_classes, identity, maskgit)
+        self.decoder.__dict__["_pt_owner"] = self
+        self.epoch_ratio = 0
+
+    def _cfg(self):
+        return [self.mot_dim, self.num_code, self.groups, self.n_classes, self.decoder.num_hidden_layers,
+                self.decoder.condi_dim - 512]
+
+    def condition(self, masked_motion, mask, audio):
+        """The part of forward before the decoder call (predictornet.py:87-100): (B,768,T')."""
+        _train_guard(self, "PredictorNet.forward")
+        mm, mk, au = _cuda_f32(masked_motion), _cuda_f32(mask), _cuda_f32(audio)
+        B, Cc, T = mm.shape
+        if Cc != self.mot_dim or tuple(mk.shape) != (B, 1, T):
+            raise RuntimeError("PredictorNet: masked_motion must be (B,%d,T) and mask (B,1,T)" % self.mot_dim)
+        Tq = T
+        for _ in range(3):
+            Tq = (Tq - 2) // 2 + 1
+        if tuple(au.shape) != (B, self.decoder.condi_dim - 512, Tq):
+            raise RuntimeError(f"PredictorNet: audio features must be (B,{self.decoder.condi_dim - 512},{Tq}), "
+                               f"got {tuple(au.shape)}")
+        h = self._handle()
+        L = _lib.lib()
+        cond = torch.empty(B, self.decoder.condi_dim, Tq, device=mm.device)
+        ws = h.workspace(L.pt_predictor_workspace_bytes(h.h, B, T))
+        check(L.pt_predictor_condition(h.h, ptr(mm), ptr(mk), ptr(au), B, T, ptr(cond), ptr(ws), ws.numel(), stream()))
+        return cond
+
+    def forward(self, masked_motion, state, mask, label, audio, text, epoch_ratio, input_codes=None,
+                distribution=False, noise=None):
+        _train_guard(self, "PredictorNet.forward")
+        if distribution:
+            raise NotImplementedError("distribution=True calls a method the reference does not define")
+        cond = self.condition(masked_motion, mask, audio)
+        return self.decoder.sample_good(label, cond, input_codes, T=self.T, noise=noise)
+
+
+class RTransformer(_HandleOwner, nn.Module):
+    """RTransformer.py:181-230."""
+    _kind = "refiner"
+
+    def __init__(self, input_dim=512, condi_dim=512, intermediate_dim=512, num_hidden_layers=6, use_label=True,
+                 n_classes=4, motion_context=False):
+        super().__init__()
+        if not (use_label and motion_context) or intermediate_dim != 512:
+            raise NotImplementedError("only use_label=True, motion_context=True, d_model=512 is on the configured path")
+        self.input_dim = input_dim
+        self.cond_dim = condi_dim
+        self.n_classes = n_classes
+        self.num_hidden_layers = num_hidden_layers
+        self.win_size = 7
+        self.motion_context = motion_context
+        self.class_embed = nn.Embedding(n_classes, intermediate_dim)
+        self.PE = PositionalEncoding(intermediate_dim, 1800)
+        self.input_conv = nn.Conv1d(input_dim, intermediate_dim, 1, 1, 0)
+        self.audio_conv = nn.Conv1d(condi_dim + 2, intermediate_dim, 1, 1, 0)
+        layer = DeepSupervisionLayer(d_model=intermediate_dim, nhead=8, groups=1, sb_every_layer=use_label)
+        self.transformer_decoder = nn.TransformerDecoder(layer, num_layers=num_hidden_layers)
+        self.output_conv = nn.Sequential(nn.Conv1d(intermediate_dim, 1024, 1), nn.ReLU(True),
+                                         nn.Conv1d(1024, input_dim, 1))
+
+    def _cfg(self):
+        return [self.input_dim, self.cond_dim, self.n_classes, self.num_hidden_layers]
+
+    def forward(self, x, condition, mask, label):
+        _train_guard(self, "RTransformer.forward")
+        x, cond, mk = _cuda_f32(x), _cuda_f32(condition), _cuda_f32(mask)
+        B, Cc, T = x.shape
+        if Cc != self.input_dim or tuple(cond.shape) != (B, self.cond_dim, T) or tuple(mk.shape) != (B, 1, T):
+            raise RuntimeError("RTransformer: expected x (B,%d,T), condition (B,%d,T), mask (B,1,T)"
+                               % (self.input_dim, self.cond_dim))
+        lab = label.to(device=x.device, dtype=torch.int64).contiguous().reshape(-1)
+        h = self._handle()
+        L = _lib.lib()
+        out = torch.empty(B, self.input_dim, T, device=x.device)
+        ws = h.workspace(L.pt_refiner_workspace_bytes(h.h, B, T))
+        check(L.pt_refiner_forward(h.h, ptr(x), ptr(cond), ptr(mk), ptr(lab), lab.numel(), B, T, ptr(out), ptr(ws),
+                                   ws.numel(), stream()))
+        return out
+
+
+def interp_blend(pred, size, gt=None, mask=None, premask=False):
+    """F.interpolate(pred, size, mode='linear') [+ gt*mask(*mask) + pred*(1-mask)] on the GPU
+    (predictor.py:445-446, refiner.py:528-529,553)."""
+    pred = _cuda_f32(pred)
+    B, Cc, Tin = pred.shape
+    out = torch.empty(B, Cc, size, device=pred.device)
+    g = m = None
+    if gt is not None:
+        g, m = _cuda_f32(gt).expand(B, Cc, size).contiguous(), _cuda_f32(mask).expand(B, 1, size).contiguous()
+    check(_lib.lib().pt_interp_blend(ptr(pred), B, Cc, Tin, size, ptr(g), ptr(m), int(premask), ptr(out), stream()))
+    return out
