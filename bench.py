@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Throughput of ProbTalk's token hot path on MI355X: generated motion frames/sec.
+
+Workload (BASELINE.json configs[3], the per-GPU share of the configuration the metric is quoted
+on): the full holistic pipeline  audio features -> AudEnc -> motion-context encoder -> 8-pass
+MaskGIT predictor -> PQ gather + conv decoder -> resize/blend -> refiner transformer -> blend,
+one micro-batch of 64 synthetic 300-frame clips per step, weights random-initialised with the
+reference's architecture (probtalk_amd.weights), inputs resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (see the field notes in DESIGN.md §Measurement).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
+MFLOP_PER_FRAME = 296.0          # full pipeline, algorithmic (2*MAC of the reference modules)
+
+
+def cpu_baseline(B=2, T=300, runs=3):
+    """The CPU oracle ("port") on a bounded sample of the same workload, on this box's host cores."""
+    from oracle import probtalk_oracle as O
+    from probtalk_amd.weights import make_input
+    from tests.helpers import ref_state_dict
+    sd_vq, sd_a, sd_p, sd_r = (ref_state_dict(k) for k in ("VQ", "AudEnc", "Predictor", "HFTransformer"))
+    Tq = T
+    for _ in range(3):
+        Tq = (Tq - 2) // 2 + 1
+    N = Tq * 4
+    aud = make_input("cpu.aud", (B, 768, T))
+    gt, mask = torch.zeros(B, 376, T), torch.zeros(B, 1, T)
+    ids = torch.arange(B) % 4
+    nq, ng = make_input("cpu.q", (8, B, N, 128), "exp"), make_input("cpu.g", (8, B, N), "gumbel")
+
+    def run():
+        body, _ = O.predictor_infer(sd_a, sd_p, sd_vq, aud, gt, mask, ids, nq, ng)
+        return O.refiner_infer(sd_r, aud, gt, mask, ids, body)
+
+    with torch.no_grad():
+        run()
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            run()
+            ts.append(time.perf_counter() - t0)
+    med = sorted(ts)[len(ts) // 2]
+    return {"value": B * T / med, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"full pipeline (oracle: AudEnc+predictor 8 passes+PQ decode+refiner), {B} clips x {T} frames, "
+                      f"fp32, median of {runs} runs after 1 warm-up ({med:.2f} s/run)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="clips per step per GPU (micro-batch of configs[3])")
+    ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    from probtalk_amd import _lib
+    from probtalk_amd.dist import OutputGatherer
+    from probtalk_amd.synthetic import build_pipeline, holistic_step
+
+    pred, ref = build_pipeline(seed=0)
+    B, T = a.batch, a.frames
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    aud = torch.randn(B, 768, T, device=dev, generator=g)          # wav2vec2-base feature shape (768-d, 30 fps)
+    gt = torch.zeros(B, 376, T, device=dev)
+    mask = torch.zeros(B, 1, T, device=dev)
+    ids = torch.randint(0, 4, (B,), device=dev, generator=g)
+    gather = OutputGatherer(world, (B, 376, T), dev) if world > 1 else None
+
+    def step():
+        out = holistic_step(pred, ref, aud, gt, mask, ids, sync=False)
+        if gather is not None:
+            gather.submit(out)          # RCCL all_gather of the outputs on a side stream, overlapped with the next step
+        return out
+
+    def fence():
+        if gather is not None:
+            gather.wait()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert bool(torch.isfinite(out).all()), "non-finite output"
+    frames = world * B * T * a.steps
+    res = {
+        "metric": "generated motion frames/sec (PQ-VAE+predictor+refiner)",
+        "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[3] per-GPU share: full holistic pipeline (AudEnc + motion-context encoder + "
+                               "8-pass MaskGIT predictor + PQ gather/decode + refiner), fp32",
+                   "clips_per_step_per_gpu": B, "frames_per_clip": T,
+                   "parallelism": f"dp{world}: clips sharded over ranks, outputs all_gathered over RCCL"},
+    }
+
+    if rank == 0 and not a.no_roofline:
+        L = _lib.lib()
+        torch.cuda.synchronize()
+        _lib.check(L.pt_prof_enable(1))
+        holistic_step(pred, ref, aud, gt, mask, ids, sync=False)
+        torch.cuda.synchronize()
+        ms, fl, ln = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_int * 3)()
+        _lib.check(L.pt_prof_read(ms, fl, ln))
+        _lib.check(L.pt_prof_enable(0))
+        tot_ms, tot_fl, tot_n = sum(ms), sum(fl), sum(ln)
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        step_ach = MFLOP_PER_FRAME * 1e6 * B * T / (1e-3 * res["ms_per_step"]) / 1e12
+        res["roofline"] = {
+            "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "kernel": "pt::gemm_f32_kernel (tap-GEMM, fp32 MFMA 32x32x2), all launches of one step",
+            "launches_per_step": tot_n, "avg_launch_ms": tot_ms / max(tot_n, 1),
+            "algorithmic_gflop_per_launch": tot_fl / max(tot_n, 1) / 1e9,
+            "gemm_ms_per_step": tot_ms,
+            "per_tile_config": {name: {"launches": ln[i], "ms": ms[i], "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] else 0.0}
+                                for i, name in enumerate(("128x128", "64x128", "64x64"))},
+            "whole_step": {"algorithmic_tflop": MFLOP_PER_FRAME * 1e6 * B * T / 1e12, "achieved": step_ach,
+                           "frac": step_ach / PEAK_F32_MFMA_TFLOPS},
+        }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -111,6 +111,11 @@ int pt_pq_search_cl(const float* z, int ldz, const float* codebooks, int rows, i
  * Q rows b*Nq+i at Q + row*ldq + head*64; K/V rows b*Nk+j likewise; O like Q. */
 int pt_attention_cl(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,
                     int Nq, int Nk, int H, void* stream);
+/* measurement aid (bench.py roofline leg): when enabled every tap-GEMM launch is bracketed by HIP events
+ * on its stream; pt_prof_read sums elapsed ms / algorithmic FLOPs / launches per tile config
+ * {128x128, 64x128, 64x64} (arrays of 3) and must be called after the stream has been synchronised. */
+int pt_prof_enable(int on);
+int pt_prof_read(double* ms3, double* flops3, int* launches3);
 /* code gather on raw buffers: idx (rows,G) int32/int64, codebooks [G][K][D] -> out [rows, ldq] (quantize_all). */
 int pt_pq_gather_cl(const void* idx, int idx_are_int64, const float* codebooks, int rows, int G, int D, int K,
                     float* out, int ldq, void* stream);

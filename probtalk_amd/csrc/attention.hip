@@ -107,9 +107,8 @@ int launch_attention(const float* Q, int ldq, const float* K, int ldk, const flo
   PT_CHECK((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)O) & 15) == 0, "attention: Q/K/O must be 16-byte aligned");
   const int qtiles = (Nq + 31) / 32;
   const int total = B * H * qtiles;
-  hipLaunchKernelGGL(attention_f32_kernel, dim3((total + 3) / 4), dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, Nq,
+  PT_LAUNCH(attention_f32_kernel, dim3((total + 3) / 4), dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, Nq,
                      Nk, H, qtiles, total, 0.125f);
-  PT_HIP(hipGetLastError());
   return 0;
 }
 

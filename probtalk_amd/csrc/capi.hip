@@ -147,7 +147,7 @@ int pt_refiner_forward(pt_model* h, const float* x, const float* condition, cons
 }
 int pt_interp_blend(const float* pred, int B, int C, int T_in, int T_out, const float* gt, const float* mask,
                     int premask, float* out, void* stream) {
-  PT_CHECK(pred && out, "pt_interp_blend: null argument");
+  PT_CHECK(out && (pred || gt), "pt_interp_blend: null argument");
   return launch_interp_blend(pred, B, C, T_in, T_out, gt, mask, premask, out, (hipStream_t)stream);
 }
 
@@ -178,6 +178,14 @@ int pt_pq_search_cl(const float* z, int ldz, const float* codebooks, int rows, i
   return launch_pq_search(z, ldz, codebooks, rows, G, D, K, idx, q, ldq, (hipStream_t)stream);
 }
 
+int pt_prof_enable(int on) {
+  prof_enable(on != 0);
+  return 0;
+}
+int pt_prof_read(double* ms3, double* flops3, int* launches3) {
+  PT_CHECK(ms3 && flops3 && launches3, "pt_prof_read: null argument");
+  return prof_read(ms3, flops3, launches3);
+}
 int pt_attention_cl(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,
                     int Nq, int Nk, int H, void* stream) {
   PT_CHECK(Q && K && V && O, "pt_attention_cl: null argument");

@@ -11,6 +11,8 @@
 // fragment reads), double-buffered LDS with register prefetch of the next stage (one barrier/stage).
 // fp32 MFMA issues one 32x32x2 per 64 cycles per SIMD, so a stage of 16*MI*NI MFMAs per wave
 // (>= 1024 cycles) hides the 2*(MI+NI) dwordx4 global loads of the next stage.
+#include <vector>
+
 #include "pt_common.h"
 
 namespace pt {
@@ -180,6 +182,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p, const i
   }
 }
 
+// ---------------------------------------------------------------------------
+// Optional per-launch timing (bench.py's roofline leg): HIP events recorded on the launch stream
+// around every GEMM launch, with the launch's algorithmic FLOPs (reference count: a folded
+// residual conv counts as the two convs the reference runs).  Off by default; never on in timed runs.
+// ---------------------------------------------------------------------------
+struct ProfRec { hipEvent_t a, b; double flops; int cfg; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_ev_pool;
+
+static hipEvent_t prof_event() {
+  if (!g_ev_pool.empty()) { hipEvent_t e = g_ev_pool.back(); g_ev_pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void prof_enable(bool on) {
+  for (auto& r : g_prof) { g_ev_pool.push_back(r.a); g_ev_pool.push_back(r.b); }
+  g_prof.clear();
+  g_prof_on = on;
+}
+// sums per tile configuration: cfg 0 = 128x128, 1 = 64x128, 2 = 64x64
+int prof_read(double* ms, double* flops, int* launches) {
+  for (int c = 0; c < 3; ++c) { ms[c] = 0; flops[c] = 0; launches[c] = 0; }
+  for (auto& r : g_prof) {
+    PT_HIP(hipEventSynchronize(r.b));
+    float t = 0.f;
+    PT_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    ms[r.cfg] += t; flops[r.cfg] += r.flops; launches[r.cfg] += 1;
+  }
+  return 0;
+}
+
 template <int MI, int NI>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
   constexpr int BM = 64 * MI, BN = 64 * NI;
@@ -193,8 +228,18 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM;
   const int tiles_n = (a.N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
-  hipLaunchKernelGGL((gemm_f32_kernel<MI, NI>), dim3(nwg), dim3(256), smem, s, a, tiles_n, nwg);
-  PT_HIP(hipGetLastError());
+  ProfRec rec;
+  if (g_prof_on) {
+    rec.a = prof_event(); rec.b = prof_event();
+    rec.flops = a.flops > 0 ? a.flops : 2.0 * a.M * a.N * a.K * a.ntaps;
+    rec.cfg = (MI == 2 && NI == 2) ? 0 : (NI == 2 ? 1 : 2);
+    PT_HIP(hipEventRecord(rec.a, s));
+  }
+  PT_LAUNCH((gemm_f32_kernel<MI, NI>), dim3(nwg), dim3(256), smem, s, a, tiles_n, nwg);
+  if (g_prof_on) {
+    PT_HIP(hipEventRecord(rec.b, s));
+    g_prof.push_back(rec);
+  }
   return 0;
 }
 

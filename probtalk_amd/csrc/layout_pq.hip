@@ -35,8 +35,7 @@ int launch_ncl_to_cl(const float* in, float* out, int B, int C, int L, int ldo, 
   const int ccover = (zero_to > col_off + C ? zero_to - col_off : C);
   PT_CHECK(col_off + ccover <= ldo, "ncl_to_cl: columns %d..%d exceed ld %d", col_off, col_off + ccover, ldo);
   dim3 grid((L + 31) / 32, (ccover + 31) / 32, B);
-  hipLaunchKernelGGL(ncl_to_cl_kernel, grid, dim3(256), 0, s, in, out, C, L, ldo, col_off, ccover);
-  PT_HIP(hipGetLastError());
+  PT_LAUNCH(ncl_to_cl_kernel, grid, dim3(256), 0, s, in, out, C, L, ldo, col_off, ccover);
   return 0;
 }
 
@@ -61,8 +60,7 @@ __global__ __launch_bounds__(256) void cl_to_ncl_kernel(const float* __restrict_
 int launch_cl_to_ncl(const float* in, int ldi, int col_off, float* out, int B, int C, int L, hipStream_t s) {
   PT_CHECK(B > 0 && C > 0 && L > 0, "cl_to_ncl: empty tensor B=%d C=%d L=%d", B, C, L);
   dim3 grid((L + 31) / 32, (C + 31) / 32, B);
-  hipLaunchKernelGGL(cl_to_ncl_kernel, grid, dim3(256), 0, s, in, ldi, col_off, out, C, L);
-  PT_HIP(hipGetLastError());
+  PT_LAUNCH(cl_to_ncl_kernel, grid, dim3(256), 0, s, in, ldi, col_off, out, C, L);
   return 0;
 }
 
@@ -207,8 +205,7 @@ int launch_pq_search(const float* z_cl, int ldz, const float* codebooks, int row
     attr = smem;
   }
   dim3 grid((rows + PQ_ROWS - 1) / PQ_ROWS, G);
-  hipLaunchKernelGGL(pq_search_kernel, grid, dim3(256), smem, s, z_cl, ldz, codebooks, rows, G, D, K, idx, q_cl, ldq);
-  PT_HIP(hipGetLastError());
+  PT_LAUNCH(pq_search_kernel, grid, dim3(256), smem, s, z_cl, ldz, codebooks, rows, G, D, K, idx, q_cl, ldq);
   return 0;
 }
 
@@ -242,9 +239,8 @@ int launch_pq_gather(const void* idx, int idx_is_i64, const float* codebooks, in
   const size_t total = (size_t)rows * (ldq / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(pq_gather_kernel, dim3(blocks), dim3(256), 0, s, idx, idx_is_i64, codebooks, rows, G, D, K, q_cl,
+  PT_LAUNCH(pq_gather_kernel, dim3(blocks), dim3(256), 0, s, idx, idx_is_i64, codebooks, rows, G, D, K, q_cl,
                      ldq, zero_to);
-  PT_HIP(hipGetLastError());
   return 0;
 }
 

@@ -26,6 +26,7 @@ struct DevConv {
   float* w = nullptr;   // [slabs][Npad][K]
   float* b = nullptr;   // [Npad]
   int N = 0, Npad = 0, K = 0, Cin = 0, slabs = 0;
+  int merged = 1;       // 2 when a residual conv was folded in (the reference runs two convs)
 };
 
 enum ConvKind { CONV_K1, CONV_K3, CONV_K7, CONV_DOWN, CONV_UP };

@@ -33,6 +33,16 @@ const char* last_error();
     }                                                                            \
   } while (0)
 
+// Kernel launch + launch-error check.  hipGetLastError() is per-thread sticky state shared with the
+// host framework's own HIP calls (PyTorch leaves benign errors behind, e.g. from device probing), so
+// it is cleared first: only this launch's status is reported.
+#define PT_LAUNCH(kernel, grid, block, smem, stream, ...)                   \
+  do {                                                                      \
+    (void)hipGetLastError();                                                \
+    hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);     \
+    PT_HIP(hipGetLastError());                                              \
+  } while (0)
+
 // ---------------------------------------------------------------------------
 // tap-GEMM: C[orow(m), n] = act( sum_t sum_k A[src(m,t), k] * W[t][n][k] + bias[n] (+pe) (+Res) )
 // Covers Linear, 1x1 conv, k3/k7 s1 conv, k4 s2 conv and (per output parity) k4 s2 ConvTranspose.
@@ -55,8 +65,11 @@ struct GemmArgs {
   int in_stride, out_stride, out_off;
   int act; float slope;
   int zero_to;                   // columns [Nout, zero_to) of C are written as zeros
+  double flops;                  // algorithmic FLOPs of this launch (profiling only; 0 = 2*M*N*K*taps)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+void prof_enable(bool on);
+int prof_read(double* ms, double* flops, int* launches);
 
 // layout
 int launch_ncl_to_cl(const float* in, float* out, int B, int C, int L, int ldo, int col_off, int zero_to, hipStream_t s);

@@ -71,8 +71,7 @@ __global__ __launch_bounds__(256) void embed_pe_kernel(const int* __restrict__ i
 }
 int launch_embed_pe(const int* ids, const float* tok, const double* pe, const double* ppe, float* x, int rows, int N,
                     int G, int vocab, hipStream_t s) {
-  hipLaunchKernelGGL(embed_pe_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, ids, tok, pe, ppe, x, rows, N, G, vocab);
-  PT_HIP(hipGetLastError());
+  PT_LAUNCH(embed_pe_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, ids, tok, pe, ppe, x, rows, N, G, vocab);
   return 0;
 }
 
@@ -106,9 +105,8 @@ __global__ __launch_bounds__(256) void ln_mod_silu_kernel(const float* __restric
 }
 int launch_ln_mod_silu(const float* h, float* out, const float* gamma, const float* beta, const float* style,
                        const int64_t* label, int n_label, int rows, int rows_per_clip, int n_classes, hipStream_t s) {
-  hipLaunchKernelGGL(ln_mod_silu_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, h, out, gamma, beta, style, label,
+  PT_LAUNCH(ln_mod_silu_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, h, out, gamma, beta, style, label,
                      n_label, rows, rows_per_clip, n_classes);
-  PT_HIP(hipGetLastError());
   return 0;
 }
 
@@ -133,8 +131,7 @@ __global__ __launch_bounds__(256) void add_ln_kernel(float* __restrict__ x, cons
   store_row(x + (size_t)row * DM, lane, r);
 }
 int launch_add_ln(float* x, const float* y, const float* gamma, const float* beta, int rows, hipStream_t s) {
-  hipLaunchKernelGGL(add_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, y, gamma, beta, rows);
-  PT_HIP(hipGetLastError());
+  PT_LAUNCH(add_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, y, gamma, beta, rows);
   return 0;
 }
 
@@ -151,8 +148,7 @@ __global__ void mask_onehot_kernel(const float* __restrict__ mask, float* __rest
   for (int c = c0 + 2; c < zero_to; ++c) p[c] = 0.f;
 }
 int launch_mask_onehot(const float* mask, float* cond, int rows, int ld, int c0, int zero_to, hipStream_t s) {
-  hipLaunchKernelGGL(mask_onehot_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, mask, cond, rows, ld, c0, zero_to);
-  PT_HIP(hipGetLastError());
+  PT_LAUNCH(mask_onehot_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, mask, cond, rows, ld, c0, zero_to);
   return 0;
 }
 
@@ -219,9 +215,8 @@ __global__ __launch_bounds__(256) void maskgit_step_kernel(const float* __restri
 int launch_maskgit_step(const float* logits, const float* noise_q, const float* noise_g, int* ids, int B, int N, int V,
                         int mask_id, int want_mask, float temp, hipStream_t s) {
   PT_CHECK(N > 0 && N <= 8192, "maskgit_step: N=%d out of range", N);
-  hipLaunchKernelGGL(maskgit_step_kernel, dim3(B), dim3(256), (size_t)N * 8, s, logits, noise_q, noise_g, ids, N, V,
+  PT_LAUNCH(maskgit_step_kernel, dim3(B), dim3(256), (size_t)N * 8, s, logits, noise_q, noise_g, ids, N, V,
                      mask_id, want_mask, temp);
-  PT_HIP(hipGetLastError());
   return 0;
 }
 
@@ -230,8 +225,7 @@ __global__ void fill_i32_kernel(int* p, int v, size_t n) {
   if (i < n) p[i] = v;
 }
 int launch_fill_i32(int* p, int v, size_t n, hipStream_t s) {
-  hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
-  PT_HIP(hipGetLastError());
+  PT_LAUNCH(fill_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
   return 0;
 }
 
@@ -247,7 +241,9 @@ __global__ __launch_bounds__(256) void interp_blend_kernel(const float* __restri
     const int t = (int)(e % T_out);
     const size_t bc = e / T_out;
     float v;
-    if (T_in == T_out) {
+    if (pred == nullptr) {
+      v = 0.f;
+    } else if (T_in == T_out) {
       v = pred[bc * T_in + t];
     } else {
       float src = scale * ((float)t + 0.5f) - 0.5f;
@@ -273,9 +269,8 @@ int launch_interp_blend(const float* pred, int B, int C, int T_in, int T_out, co
   const size_t total = (size_t)B * C * T_out;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(interp_blend_kernel, dim3(blocks), dim3(256), 0, s, pred, T_in, T_out, gt, mask, premask, out, C,
+  PT_LAUNCH(interp_blend_kernel, dim3(blocks), dim3(256), 0, s, pred, T_in, T_out, gt, mask, premask, out, C,
                      total);
-  PT_HIP(hipGetLastError());
   return 0;
 }
 

@@ -80,6 +80,7 @@ static int pack_conv(Model& m, DevConv& out, const std::string& w1, const std::s
   out.K = round_up(Cin, 32);
   out.Npad = round_up(N, 128);
   out.slabs = kt;
+  out.merged = W2 ? 2 : 1;
   std::vector<float> hw((size_t)kt * out.Npad * out.K, 0.f), hb(out.Npad, 0.f);
   const int dim = N / 2;
   auto prow = [&](int n) {
@@ -227,10 +228,12 @@ int run_conv(const DevConv& c, ConvKind kind, const float* A, int lda, int B, in
   if (Lout_p) *Lout_p = Lout;
   if (kind != CONV_UP) {
     a.Lgrid = Lout; a.M = B * Lout;
+    a.flops = 2.0 * a.M * c.N * c.Cin * a.ntaps * c.merged;
     return launch_gemm(a, s);
   }
   // ConvTranspose1d k4 s2 p1: out[2q] = x[q] w1 + x[q-1] w3 ; out[2q+1] = x[q] w2 + x[q+1] w0
   a.Lgrid = Lin; a.M = B * Lin; a.out_stride = 2; a.ntaps = 2;
+  a.flops = 2.0 * a.M * c.N * c.Cin * 2 * c.merged;
   a.out_off = 0; a.tap_d[0] = 0; a.tap_w[0] = 1; a.tap_d[1] = -1; a.tap_w[1] = 3;
   if (launch_gemm(a, s)) return 1;
   a.out_off = 1; a.tap_d[0] = 0; a.tap_w[0] = 2; a.tap_d[1] = 1; a.tap_w[1] = 0;

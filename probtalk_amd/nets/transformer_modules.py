@@ -314,11 +314,18 @@ class RTransformer(_HandleOwner, nn.Module):
 def interp_blend(pred, size, gt=None, mask=None, premask=False):
     """F.interpolate(pred, size, mode='linear') [+ gt*mask(*mask) + pred*(1-mask)] on the GPU
     (predictor.py:445-446, refiner.py:528-529,553)."""
-    pred = _cuda_f32(pred)
-    B, Cc, Tin = pred.shape
-    out = torch.empty(B, Cc, size, device=pred.device)
     g = m = None
     if gt is not None:
-        g, m = _cuda_f32(gt).expand(B, Cc, size).contiguous(), _cuda_f32(mask).expand(B, 1, size).contiguous()
+        g, m = _cuda_f32(gt), _cuda_f32(mask)
+    if pred is None:                       # plain gt * mask
+        B, Cc, Tin = g.shape
+        dev = g.device
+    else:
+        pred = _cuda_f32(pred)
+        B, Cc, Tin = pred.shape
+        dev = pred.device
+    if g is not None and (tuple(g.shape) != (B, Cc, size) or tuple(m.shape) != (B, 1, size)):
+        raise RuntimeError("interp_blend: gt must be (B,C,size) and mask (B,1,size)")
+    out = torch.empty(B, Cc, size, device=dev)
     check(_lib.lib().pt_interp_blend(ptr(pred), B, Cc, Tin, size, ptr(g), ptr(m), int(premask), ptr(out), stream()))
     return out

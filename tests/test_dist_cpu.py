@@ -1,0 +1,52 @@
+"""world_size-2 gloo tests of the batch sharding / output gather plumbing (no GPU)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from probtalk_amd.dist import OutputGatherer, gather_batch, shard_batch, shard_range
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 64, 4096):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_clips):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(n_clips * 6, dtype=torch.float32).reshape(n_clips, 2, 3)
+        mine = shard_batch(full)
+        lo, hi = shard_range(n_clips, rank, world)
+        assert torch.equal(mine, full[lo:hi])
+        out = mine * 2 + 1                      # stand-in for the per-rank pipeline
+        back = gather_batch(out, n_total=n_clips)
+        assert torch.equal(back, full * 2 + 1)
+        if n_clips % world == 0:
+            g = OutputGatherer(world, tuple(out.shape), "cpu")
+            got = g.submit(out)
+            g.wait()
+            assert torch.equal(got, full * 2 + 1)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_gather_world2_even_and_ragged():
+    for n in (8, 7):
+        mp.spawn(_worker, args=(2, _free_port(), n), nprocs=2, join=True)
