@@ -25,6 +25,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak (never the 2:1-sparsity figure)
 MFLOP_PER_FRAME = 296.0          # full pipeline, algorithmic (2*MAC of the reference modules)
 
 
@@ -67,6 +68,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="clips per step per GPU (micro-batch of configs[3])")
     ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--dtype", choices=("bf16", "f32"), default="bf16",
+                    help="arithmetic of the predictor/refiner transformers (conv stacks and PQ stay fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -84,6 +87,9 @@ def main():
     from probtalk_amd.synthetic import build_pipeline, holistic_step
 
     pred, ref = build_pipeline(seed=0)
+    if a.dtype == "bf16":
+        pred.Predictor.set_precision("bf16")
+        ref.RTransformer.set_precision("bf16")
     B, T = a.batch, a.frames
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     aud = torch.randn(B, 768, T, device=dev, generator=g)          # wav2vec2-base feature shape (768-d, 30 fps)
@@ -123,9 +129,10 @@ def main():
         "metric": "generated motion frames/sec (PQ-VAE+predictor+refiner)",
         "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": "configs[3] per-GPU share: full holistic pipeline (AudEnc + motion-context encoder + "
-                               "8-pass MaskGIT predictor + PQ gather/decode + refiner), fp32",
+                               "8-pass MaskGIT predictor + PQ gather/decode + refiner); "
+                               + ("transformers bf16 MFMA / fp32 accumulate, conv stacks fp32" if a.dtype == "bf16" else "fp32"),
                    "clips_per_step_per_gpu": B, "frames_per_clip": T,
                    "parallelism": f"dp{world}: clips sharded over ranks, outputs all_gathered over RCCL"},
     }
@@ -136,23 +143,28 @@ def main():
         _lib.check(L.pt_prof_enable(1))
         holistic_step(pred, ref, aud, gt, mask, ids, sync=False)
         torch.cuda.synchronize()
-        ms, fl, ln = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_int * 3)()
+        ms, fl, ln = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_int * 6)()
         _lib.check(L.pt_prof_read(ms, fl, ln))
         _lib.check(L.pt_prof_enable(0))
-        tot_ms, tot_fl, tot_n = sum(ms), sum(fl), sum(ln)
+        names = ("f32 128x128", "f32 64x128", "f32 64x64", "bf16 128x128", "bf16 64x128", "bf16 64x64")
+        dom = range(3, 6) if a.dtype == "bf16" else range(0, 3)     # the dominant kernel family of this mode
+        peak = PEAK_BF16_MFMA_TFLOPS if a.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        kname = "pt::gemm_bf16_kernel (tap-GEMM, bf16 MFMA 32x32x16)" if a.dtype == "bf16" else \
+            "pt::gemm_f32_kernel (tap-GEMM, fp32 MFMA 32x32x2)"
+        tot_ms, tot_fl, tot_n = sum(ms[i] for i in dom), sum(fl[i] for i in dom), sum(ln[i] for i in dom)
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        step_ach = MFLOP_PER_FRAME * 1e6 * B * T / (1e-3 * res["ms_per_step"]) / 1e12
+        step_tflop = MFLOP_PER_FRAME * 1e6 * B * T / 1e12
         res["roofline"] = {
-            "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-            "kernel": "pt::gemm_f32_kernel (tap-GEMM, fp32 MFMA 32x32x2), all launches of one step",
+            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            "kernel": kname + ", all launches of one step",
             "launches_per_step": tot_n, "avg_launch_ms": tot_ms / max(tot_n, 1),
             "algorithmic_gflop_per_launch": tot_fl / max(tot_n, 1) / 1e9,
-            "gemm_ms_per_step": tot_ms,
-            "per_tile_config": {name: {"launches": ln[i], "ms": ms[i], "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] else 0.0}
-                                for i, name in enumerate(("128x128", "64x128", "64x64"))},
-            "whole_step": {"algorithmic_tflop": MFLOP_PER_FRAME * 1e6 * B * T / 1e12, "achieved": step_ach,
-                           "frac": step_ach / PEAK_F32_MFMA_TFLOPS},
+            "kernel_ms_per_step": tot_ms,
+            "per_kernel_config": {names[i]: {"launches": ln[i], "ms": ms[i], "gflop": fl[i] / 1e9,
+                                             "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] else 0.0}
+                                  for i in range(6) if ln[i]},
+            "whole_step": {"algorithmic_tflop": step_tflop,
+                           "achieved_tflops": step_tflop / (1e-3 * res["ms_per_step"])},
         }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()

@@ -37,6 +37,10 @@ pt_model* pt_model_create(const char* kind, const int* cfg, int ncfg);
  * i.e. what `module.state_dict()` / a ckpt-*.pth holds (vq_teacher.py:103-114, predictor.py:128-143).
  * dtype: 0 = float32, 1 = float64 (positional-encoding tables). */
 int pt_model_set_tensor(pt_model* m, const char* name, const void* host_data, const int64_t* shape, int ndim, int dtype);
+/* Arithmetic of the transformer GEMMs / attention: 0 = fp32 (default; parity path, 1e-4), 1 = bf16 operands with
+ * fp32 accumulation, fp32 residual stream and LayerNorm (BASELINE configs[2]; tolerance 1e-2).  Predictor and
+ * refiner only; call before pt_model_finalize. */
+int pt_model_set_precision(pt_model* m, int precision);
 /* Fold BatchNorm(eval) into the convs, repack, upload.  Replaces nn.Module.load_state_dict + .to(device). */
 int pt_model_finalize(pt_model* m);
 void pt_model_destroy(pt_model* m);
@@ -112,10 +116,10 @@ int pt_pq_search_cl(const float* z, int ldz, const float* codebooks, int rows, i
 int pt_attention_cl(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,
                     int Nq, int Nk, int H, void* stream);
 /* measurement aid (bench.py roofline leg): when enabled every tap-GEMM launch is bracketed by HIP events
- * on its stream; pt_prof_read sums elapsed ms / algorithmic FLOPs / launches per tile config
- * {128x128, 64x128, 64x64} (arrays of 3) and must be called after the stream has been synchronised. */
+ * on its stream; pt_prof_read sums elapsed ms / algorithmic FLOPs / launches per kernel config
+ * {fp32 128x128, 64x128, 64x64, bf16 128x128, 64x128, 64x64} (arrays of 6); call it after synchronising. */
 int pt_prof_enable(int on);
-int pt_prof_read(double* ms3, double* flops3, int* launches3);
+int pt_prof_read(double* ms6, double* flops6, int* launches6);
 /* code gather on raw buffers: idx (rows,G) int32/int64, codebooks [G][K][D] -> out [rows, ldq] (quantize_all). */
 int pt_pq_gather_cl(const void* idx, int idx_are_int64, const float* codebooks, int rows, int G, int D, int K,
                     float* out, int ldq, void* stream);

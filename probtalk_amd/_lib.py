@@ -25,6 +25,7 @@ def _proto(lib):
     lib.pt_model_create.argtypes = [C.c_char_p, C.POINTER(C.c_int), i]
     lib.pt_model_set_tensor.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), i, i]
     lib.pt_model_finalize.argtypes = [vp]
+    lib.pt_model_set_precision.argtypes = [vp, i]
     lib.pt_model_destroy.argtypes = [vp]
     lib.pt_model_destroy.restype = None
     for name in ("pt_vqvae_workspace_bytes", "pt_cond_encoder_workspace_bytes", "pt_predictor_workspace_bytes",
@@ -58,6 +59,7 @@ def _proto(lib):
 
 EXPORTS = [
     "pt_last_error", "pt_version", "pt_model_create", "pt_model_set_tensor", "pt_model_finalize", "pt_model_destroy",
+    "pt_model_set_precision",
     "pt_vqvae_workspace_bytes", "pt_vqvae_encode", "pt_vqvae_decode", "pt_vqvae_decode_codes", "pt_pq_quantize",
     "pt_pq_quantize_all", "pt_cond_encoder_workspace_bytes", "pt_cond_encoder_forward",
     "pt_predictor_workspace_bytes", "pt_predictor_condition", "pt_predictor_logits", "pt_predictor_sample",
@@ -103,7 +105,7 @@ def dev_f32(t, device=None):
 class Handle:
     """Owner of one pt_model plus a growing device workspace."""
 
-    def __init__(self, kind, cfg, state_dict, prefix=""):
+    def __init__(self, kind, cfg, state_dict, prefix="", precision="fp32"):
         L = lib()
         if not torch.cuda.is_available():
             raise RuntimeError("probtalk_amd needs a HIP device (no CPU fallback)")
@@ -122,7 +124,12 @@ class Handle:
                 t, dt = t.to(torch.float32), 0
             shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
             check(L.pt_model_set_tensor(self.h, (prefix + k).encode(), C.c_void_p(t.data_ptr()), shape, t.dim(), dt))
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        if precision == "bf16":
+            check(L.pt_model_set_precision(self.h, 1))
         check(L.pt_model_finalize(self.h))
+        self.precision = precision
         self._ws = None
 
     def workspace(self, nbytes):

@@ -51,6 +51,16 @@ int pt_model_set_tensor(pt_model* h, const char* name, const void* host_data, co
   return 0;
 }
 
+int pt_model_set_precision(pt_model* h, int precision) {
+  PT_CHECK(h, "pt_model_set_precision: null model");
+  PT_CHECK(!h->m.finalized, "pt_model_set_precision: model already finalized");
+  PT_CHECK(precision == 0 || precision == 1, "pt_model_set_precision: %d unsupported (0 = fp32, 1 = bf16)", precision);
+  PT_CHECK(precision == 0 || h->m.kind == "predictor" || h->m.kind == "refiner",
+           "pt_model_set_precision: bf16 mode exists for the predictor and refiner transformers only");
+  h->m.precision = precision;
+  return 0;
+}
+
 int pt_model_finalize(pt_model* h) {
   PT_CHECK(h, "pt_model_finalize: null model");
   return finalize_model(h->m);
@@ -182,9 +192,9 @@ int pt_prof_enable(int on) {
   prof_enable(on != 0);
   return 0;
 }
-int pt_prof_read(double* ms3, double* flops3, int* launches3) {
-  PT_CHECK(ms3 && flops3 && launches3, "pt_prof_read: null argument");
-  return prof_read(ms3, flops3, launches3);
+int pt_prof_read(double* ms6, double* flops6, int* launches6) {
+  PT_CHECK(ms6 && flops6 && launches6, "pt_prof_read: null argument");
+  return prof_read(ms6, flops6, launches6);
 }
 int pt_attention_cl(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,
                     int Nq, int Nk, int H, void* stream) {

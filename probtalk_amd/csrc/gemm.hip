@@ -198,14 +198,26 @@ static hipEvent_t prof_event() {
   (void)hipEventCreate(&e);
   return e;
 }
+bool prof_is_on() { return g_prof_on; }
 void prof_enable(bool on) {
   for (auto& r : g_prof) { g_ev_pool.push_back(r.a); g_ev_pool.push_back(r.b); }
   g_prof.clear();
   g_prof_on = on;
 }
-// sums per tile configuration: cfg 0 = 128x128, 1 = 64x128, 2 = 64x64
+void prof_record_begin(hipStream_t s, double flops, int cfg, void** tok) {
+  ProfRec* r = new ProfRec{prof_event(), prof_event(), flops, cfg};
+  (void)hipEventRecord(r->a, s);
+  *tok = r;
+}
+void prof_record_end(hipStream_t s, void* tok) {
+  ProfRec* r = (ProfRec*)tok;
+  (void)hipEventRecord(r->b, s);
+  g_prof.push_back(*r);
+  delete r;
+}
+// sums per kernel configuration: 0..2 = fp32 128x128 / 64x128 / 64x64, 3..5 = bf16 same tiles
 int prof_read(double* ms, double* flops, int* launches) {
-  for (int c = 0; c < 3; ++c) { ms[c] = 0; flops[c] = 0; launches[c] = 0; }
+  for (int c = 0; c < PROF_CFGS; ++c) { ms[c] = 0; flops[c] = 0; launches[c] = 0; }
   for (auto& r : g_prof) {
     PT_HIP(hipEventSynchronize(r.b));
     float t = 0.f;
@@ -228,18 +240,11 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM;
   const int tiles_n = (a.N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
-  ProfRec rec;
-  if (g_prof_on) {
-    rec.a = prof_event(); rec.b = prof_event();
-    rec.flops = a.flops > 0 ? a.flops : 2.0 * a.M * a.N * a.K * a.ntaps;
-    rec.cfg = (MI == 2 && NI == 2) ? 0 : (NI == 2 ? 1 : 2);
-    PT_HIP(hipEventRecord(rec.a, s));
-  }
+  void* tok = nullptr;
+  if (g_prof_on) prof_record_begin(s, a.flops > 0 ? a.flops : 2.0 * a.M * a.N * a.K * a.ntaps,
+                                   (MI == 2 && NI == 2) ? 0 : (NI == 2 ? 1 : 2), &tok);
   PT_LAUNCH((gemm_f32_kernel<MI, NI>), dim3(nwg), dim3(256), smem, s, a, tiles_n, nwg);
-  if (g_prof_on) {
-    PT_HIP(hipEventRecord(rec.b, s));
-    g_prof.push_back(rec);
-  }
+  if (tok) prof_record_end(s, tok);
   return 0;
 }
 

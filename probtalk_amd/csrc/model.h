@@ -27,6 +27,8 @@ struct DevConv {
   float* b = nullptr;   // [Npad]
   int N = 0, Npad = 0, K = 0, Cin = 0, slabs = 0;
   int merged = 1;       // 2 when a residual conv was folded in (the reference runs two convs)
+  unsigned short* wb = nullptr;  // bf16 copy [Npad][Kb] (1x1 / Linear layers of bf16-mode models)
+  int Kb = 0;                    // round_up(Cin, 64)
 };
 
 enum ConvKind { CONV_K1, CONV_K3, CONV_K7, CONV_DOWN, CONV_UP };
@@ -56,6 +58,7 @@ struct Model {
   std::map<std::string, HostTensor> sd;
   std::vector<void*> allocs;
   bool finalized = false;
+  int precision = 0;    // 0 = fp32 everywhere; 1 = bf16 operands in the transformer GEMMs / attention
   VQVAE vq;
   CondEncoder ce;
   struct Predictor* pred = nullptr;

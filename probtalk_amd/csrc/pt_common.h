@@ -68,8 +68,31 @@ struct GemmArgs {
   double flops;                  // algorithmic FLOPs of this launch (profiling only; 0 = 2*M*N*K*taps)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+constexpr int PROF_CFGS = 6;
 void prof_enable(bool on);
 int prof_read(double* ms, double* flops, int* launches);
+
+// bf16-operand variant (gemm_bf16.hip): A and W are bf16 bit patterns, accumulation and epilogue fp32,
+// output fp32 (C) and/or bf16 (Cb).  K is a multiple of 64.
+struct GemmArgsB {
+  const unsigned short* A; int lda;
+  const unsigned short* W;
+  const float* bias;
+  const float* Res; int ldr;
+  float* C; int ldc;
+  unsigned short* Cb; int ldcb;
+  const double* pe; int pe_period;
+  int M, N, K, Npad;
+  int ntaps;
+  int tap_d[MAX_TAPS];
+  int tap_w[MAX_TAPS];
+  int Lgrid, Lin, Lout;
+  int in_stride, out_stride, out_off;
+  int act; float slope;
+  int zero_to;
+  double flops;
+};
+int launch_gemm_bf16(const GemmArgsB& a, hipStream_t s);
 
 // layout
 int launch_ncl_to_cl(const float* in, float* out, int B, int C, int L, int ldo, int col_off, int zero_to, hipStream_t s);

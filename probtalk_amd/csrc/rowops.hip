@@ -33,6 +33,14 @@ __device__ __forceinline__ void store_row(float* p, int lane, const Row8& r) {
   *reinterpret_cast<f32x4*>(p + lane * 4) = r.a;
   *reinterpret_cast<f32x4*>(p + 256 + lane * 4) = r.b;
 }
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_row_bf16(unsigned short* p, int lane, const Row8& r) {
+  bf16x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = (__bf16)r.a[i]; b[i] = (__bf16)r.b[i]; }
+  *reinterpret_cast<bf16x4*>(p + lane * 4) = a;
+  *reinterpret_cast<bf16x4*>(p + 256 + lane * 4) = b;
+}
 // LayerNorm statistics of one 512-wide row held across the wave (two-pass, biased variance, eps 1e-5)
 __device__ __forceinline__ void ln_stats(const Row8& r, float& mean, float& rstd) {
   float s = 0.f;
@@ -51,7 +59,8 @@ __device__ __forceinline__ void ln_stats(const Row8& r, float& mean, float& rstd
 // x[row] = float(double(tok_emb[id]) + (PE[t+1] + PPE[g+1]))   (PTransformer.py:659-679)
 __global__ __launch_bounds__(256) void embed_pe_kernel(const int* __restrict__ ids, const float* __restrict__ tok,
                                                        const double* __restrict__ pe, const double* __restrict__ ppe,
-                                                       float* __restrict__ x, int rows, int N, int G, int vocab) {
+                                                       float* __restrict__ x, unsigned short* __restrict__ xb,
+                                                       int rows, int N, int G, int vocab) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const int n = row % N, t = n / G, g = n - t * G;
@@ -67,17 +76,24 @@ __global__ __launch_bounds__(256) void embed_pe_kernel(const int* __restrict__ i
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = (float)((double)e[c + i] + (p1[c + i] + p2[c + i]));
     *reinterpret_cast<f32x4*>(x + (size_t)row * DM + c) = o;
+    if (xb) {
+      bf16x4 ob;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ob[i] = (__bf16)o[i];
+      *reinterpret_cast<bf16x4*>(xb + (size_t)row * DM + c) = ob;
+    }
   }
 }
-int launch_embed_pe(const int* ids, const float* tok, const double* pe, const double* ppe, float* x, int rows, int N,
-                    int G, int vocab, hipStream_t s) {
-  PT_LAUNCH(embed_pe_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, ids, tok, pe, ppe, x, rows, N, G, vocab);
+int launch_embed_pe(const int* ids, const float* tok, const double* pe, const double* ppe, float* x,
+                    unsigned short* xb, int rows, int N, int G, int vocab, hipStream_t s) {
+  PT_LAUNCH(embed_pe_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, ids, tok, pe, ppe, x, xb, rows, N, G, vocab);
   return 0;
 }
 
 // out = SiLU(LN(h; g, b) * (1 + scale[label]) + shift[label])     (PTransformer.py:134-139)
 // style: [n_classes][2*DM] = emb_layers_2(SiLU(class_embed[c])) precomputed at load; label per clip.
 __global__ __launch_bounds__(256) void ln_mod_silu_kernel(const float* __restrict__ h, float* __restrict__ out,
+                                                          unsigned short* __restrict__ outb,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           const float* __restrict__ style,
@@ -101,11 +117,13 @@ __global__ __launch_bounds__(256) void ln_mod_silu_kernel(const float* __restric
     o.a[i] = ya / (1.f + expf(-ya));
     o.b[i] = yb / (1.f + expf(-yb));
   }
-  store_row(out + (size_t)row * DM, lane, o);
+  if (out) store_row(out + (size_t)row * DM, lane, o);
+  if (outb) store_row_bf16(outb + (size_t)row * DM, lane, o);
 }
-int launch_ln_mod_silu(const float* h, float* out, const float* gamma, const float* beta, const float* style,
-                       const int64_t* label, int n_label, int rows, int rows_per_clip, int n_classes, hipStream_t s) {
-  PT_LAUNCH(ln_mod_silu_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, h, out, gamma, beta, style, label,
+int launch_ln_mod_silu(const float* h, float* out, unsigned short* outb, const float* gamma, const float* beta,
+                       const float* style, const int64_t* label, int n_label, int rows, int rows_per_clip,
+                       int n_classes, hipStream_t s) {
+  PT_LAUNCH(ln_mod_silu_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, h, out, outb, gamma, beta, style, label,
                      n_label, rows, rows_per_clip, n_classes);
   return 0;
 }
@@ -113,7 +131,7 @@ int launch_ln_mod_silu(const float* h, float* out, const float* gamma, const flo
 // x = LN(x + y; g, b)   (post-LN residual, PTransformer.py:329-331)
 __global__ __launch_bounds__(256) void add_ln_kernel(float* __restrict__ x, const float* __restrict__ y,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     int rows) {
+                                                     int rows, unsigned short* __restrict__ xb) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   Row8 r = load_row(x + (size_t)row * DM, lane);
@@ -129,9 +147,11 @@ __global__ __launch_bounds__(256) void add_ln_kernel(float* __restrict__ x, cons
     r.b[i] = (r.b[i] - mean) * rstd * g.b[i] + b.b[i];
   }
   store_row(x + (size_t)row * DM, lane, r);
+  if (xb) store_row_bf16(xb + (size_t)row * DM, lane, r);
 }
-int launch_add_ln(float* x, const float* y, const float* gamma, const float* beta, int rows, hipStream_t s) {
-  PT_LAUNCH(add_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, y, gamma, beta, rows);
+int launch_add_ln(float* x, const float* y, const float* gamma, const float* beta, int rows, unsigned short* xb,
+                  hipStream_t s) {
+  PT_LAUNCH(add_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, y, gamma, beta, rows, xb);
   return 0;
 }
 

@@ -103,6 +103,20 @@ static int pack_conv(Model& m, DevConv& out, const std::string& w1, const std::s
     hb[pr] = (float)bv;
   }
   if (upload(m, hw, &out.w)) return 1;
+  if (m.precision == 1 && kt == 1 && !gated) {
+    // bf16 copy (round to nearest even) with K padded to the bf16 kernel's 64-element stage
+    out.Kb = round_up(Cin, 64);
+    std::vector<unsigned short> hwb((size_t)out.Npad * out.Kb, 0);
+    for (int n = 0; n < N; ++n)
+      for (int c = 0; c < Cin; ++c) {
+        uint32_t u;
+        const float f = hw[(size_t)n * out.K + c];
+        memcpy(&u, &f, 4);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        hwb[(size_t)n * out.Kb + c] = (unsigned short)(u >> 16);
+      }
+    if (upload(m, hwb, &out.wb)) return 1;
+  }
   return upload(m, hb, &out.b);
 }
 

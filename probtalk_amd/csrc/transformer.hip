@@ -12,11 +12,19 @@
 
 namespace pt {
 
-int launch_embed_pe(const int* ids, const float* tok, const double* pe, const double* ppe, float* x, int rows, int N,
-                    int G, int vocab, hipStream_t s);
-int launch_ln_mod_silu(const float* h, float* out, const float* gamma, const float* beta, const float* style,
-                       const int64_t* label, int n_label, int rows, int rows_per_clip, int n_classes, hipStream_t s);
-int launch_add_ln(float* x, const float* y, const float* gamma, const float* beta, int rows, hipStream_t s);
+int launch_embed_pe(const int* ids, const float* tok, const double* pe, const double* ppe, float* x,
+                    unsigned short* xb, int rows, int N, int G, int vocab, hipStream_t s);
+int launch_ln_mod_silu(const float* h, float* out, unsigned short* outb, const float* gamma, const float* beta,
+                       const float* style, const int64_t* label, int n_label, int rows, int rows_per_clip,
+                       int n_classes, hipStream_t s);
+int launch_add_ln(float* x, const float* y, const float* gamma, const float* beta, int rows, unsigned short* xb,
+                  hipStream_t s);
+int launch_cvt_f32_bf16(const float* in, int ldi, unsigned short* out, int ldo, int rows, int cols, int zero_to,
+                        hipStream_t s);
+int launch_vt(const unsigned short* V, int ldv, unsigned short* VT, int B, int Nk, int H, hipStream_t s);
+int launch_attention_bf16(const unsigned short* Q, int ldq, const unsigned short* K, int ldk,
+                          const unsigned short* VT, unsigned short* O, int ldo, int B, int Nq, int Nk, int H,
+                          hipStream_t s);
 int launch_mask_onehot(const float* mask, float* cond, int rows, int ld, int c0, int zero_to, hipStream_t s);
 int launch_maskgit_step(const float* logits, const float* noise_q, const float* noise_g, int* ids, int B, int N, int V,
                         int mask_id, int want_mask, float temp, hipStream_t s);
@@ -223,47 +231,102 @@ int finalize_transformer_models(Model& m) {
 }
 
 // ------------------------------------------------------------------ decoder layer
-struct TBufs { float *x, *qkv, *att, *t, *hb; };
+// Buffers of one transformer stack.  fp32 mode uses x/qkv/att/t/hb as floats; bf16 mode keeps the residual
+// stream x and the pre-LayerNorm sub-layer outputs t in fp32 and everything that only feeds a GEMM or the
+// attention core (xb, qkv, att, hb) in bf16.
+typedef unsigned short bf16_t;
+struct TBufs {
+  float *x = nullptr, *qkv = nullptr, *att = nullptr, *t = nullptr, *hb = nullptr;   // fp32 mode
+  bf16_t *xb = nullptr, *qkvb = nullptr, *attb = nullptr, *hbb = nullptr, *vts = nullptr;  // bf16 mode
+};
 
 static inline int lin(const DevConv& c, const float* A, int lda, int rows, float* C, int ldc, int act, float slope,
                       hipStream_t s, const double* pe = nullptr, int period = 0) {
   return run_conv(c, CONV_K1, A, lda, 1, rows, C, ldc, act, slope, nullptr, 0, s, nullptr, -1, pe, period);
 }
 
+// bf16-operand Linear: A bf16 [rows, lda] -> C fp32 and/or Cb bf16
+static int lin_b(const DevConv& c, const bf16_t* A, int lda, int rows, float* C, int ldc, bf16_t* Cb, int ldcb, int act,
+                 float slope, hipStream_t s, const double* pe = nullptr, int period = 0) {
+  PT_CHECK(c.wb != nullptr, "bf16 weights were not packed for this layer");
+  PT_CHECK(lda >= c.Kb, "lin_b: input leading dim %d < packed K %d", lda, c.Kb);
+  GemmArgsB a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.W = c.wb; a.bias = c.b; a.C = C; a.ldc = ldc; a.Cb = Cb; a.ldcb = ldcb;
+  a.pe = pe; a.pe_period = period;
+  a.M = rows; a.N = c.N; a.K = c.Kb; a.Npad = c.Npad;
+  a.ntaps = 1; a.Lgrid = rows; a.Lin = rows; a.Lout = rows; a.in_stride = 1; a.out_stride = 1;
+  a.act = act; a.slope = slope;
+  a.zero_to = 0;
+  a.flops = 2.0 * rows * c.N * c.Cin;
+  return launch_gemm_bf16(a, s);
+}
+
 static int style_then_ln(const StyleW& st, const LNW& ln, TBufs& b, int rows, int rows_per_clip, const int64_t* label,
-                         int n_label, int n_classes, hipStream_t s) {
+                         int n_label, int n_classes, bool bf, hipStream_t s) {
   // b.t holds the sub-layer output; x <- LN(x + style(t))
-  if (launch_ln_mod_silu(b.t, b.att, st.ln.g, st.ln.b, st.table, label, n_label, rows, rows_per_clip, n_classes, s)) return 1;
-  if (lin(st.out, b.att, DM, rows, b.t, DM, ACT_NONE, 1.f, s)) return 1;
-  return launch_add_ln(b.x, b.t, ln.g, ln.b, rows, s);
+  if (!bf) {
+    if (launch_ln_mod_silu(b.t, b.att, nullptr, st.ln.g, st.ln.b, st.table, label, n_label, rows, rows_per_clip,
+                           n_classes, s)) return 1;
+    if (lin(st.out, b.att, DM, rows, b.t, DM, ACT_NONE, 1.f, s)) return 1;
+    return launch_add_ln(b.x, b.t, ln.g, ln.b, rows, nullptr, s);
+  }
+  if (launch_ln_mod_silu(b.t, nullptr, b.attb, st.ln.g, st.ln.b, st.table, label, n_label, rows, rows_per_clip,
+                         n_classes, s)) return 1;
+  if (lin_b(st.out, b.attb, DM, rows, b.t, DM, nullptr, 0, ACT_NONE, 1.f, s)) return 1;
+  return launch_add_ln(b.x, b.t, ln.g, ln.b, rows, b.xb, s);
 }
 
-static int decoder_layer(const DecLayer& L, TBufs& b, const float* kv, int B, int Nq, int Nk, const int64_t* label,
-                         int n_label, int n_classes, hipStream_t s) {
+// kv: fp32 mode [Rm, 1024] floats (K | V); bf16 mode the same in bf16 plus vt_cross = V^T per head
+static int decoder_layer(const DecLayer& L, TBufs& b, const void* kv, const bf16_t* vt_cross, int B, int Nq, int Nk,
+                         const int64_t* label, int n_label, int n_classes, bool bf, hipStream_t s) {
   const int R = B * Nq;
-  // self attention
-  if (lin(L.sa_in, b.x, DM, R, b.qkv, 3 * DM, ACT_NONE, 1.f, s)) return 1;
-  if (launch_attention(b.qkv, 3 * DM, b.qkv + DM, 3 * DM, b.qkv + 2 * DM, 3 * DM, b.att, DM, B, Nq, Nq, NH, s)) return 1;
-  if (lin(L.sa_out, b.att, DM, R, b.t, DM, ACT_NONE, 1.f, s)) return 1;
-  if (style_then_ln(L.st[0], L.n1, b, R, Nq, label, n_label, n_classes, s)) return 1;
-  // cross attention over the condition memory (K/V precomputed)
-  if (lin(L.ca_q, b.x, DM, R, b.qkv, DM, ACT_NONE, 1.f, s)) return 1;
-  if (launch_attention(b.qkv, DM, kv, 2 * DM, kv + DM, 2 * DM, b.att, DM, B, Nq, Nk, NH, s)) return 1;
-  if (lin(L.ca_out, b.att, DM, R, b.t, DM, ACT_NONE, 1.f, s)) return 1;
-  if (style_then_ln(L.st[1], L.n2, b, R, Nq, label, n_label, n_classes, s)) return 1;
-  // feed forward
-  if (lin(L.ff1, b.x, DM, R, b.hb, FF, ACT_LEAKY, 0.f, s)) return 1;
-  if (lin(L.ff2, b.hb, FF, R, b.t, DM, ACT_NONE, 1.f, s)) return 1;
-  return style_then_ln(L.st[2], L.n3, b, R, Nq, label, n_label, n_classes, s);
+  if (!bf) {
+    const float* kvf = (const float*)kv;
+    if (lin(L.sa_in, b.x, DM, R, b.qkv, 3 * DM, ACT_NONE, 1.f, s)) return 1;
+    if (launch_attention(b.qkv, 3 * DM, b.qkv + DM, 3 * DM, b.qkv + 2 * DM, 3 * DM, b.att, DM, B, Nq, Nq, NH, s)) return 1;
+    if (lin(L.sa_out, b.att, DM, R, b.t, DM, ACT_NONE, 1.f, s)) return 1;
+    if (style_then_ln(L.st[0], L.n1, b, R, Nq, label, n_label, n_classes, bf, s)) return 1;
+    if (lin(L.ca_q, b.x, DM, R, b.qkv, DM, ACT_NONE, 1.f, s)) return 1;
+    if (launch_attention(b.qkv, DM, kvf, 2 * DM, kvf + DM, 2 * DM, b.att, DM, B, Nq, Nk, NH, s)) return 1;
+    if (lin(L.ca_out, b.att, DM, R, b.t, DM, ACT_NONE, 1.f, s)) return 1;
+    if (style_then_ln(L.st[1], L.n2, b, R, Nq, label, n_label, n_classes, bf, s)) return 1;
+    if (lin(L.ff1, b.x, DM, R, b.hb, FF, ACT_LEAKY, 0.f, s)) return 1;
+    if (lin(L.ff2, b.hb, FF, R, b.t, DM, ACT_NONE, 1.f, s)) return 1;
+    return style_then_ln(L.st[2], L.n3, b, R, Nq, label, n_label, n_classes, bf, s);
+  }
+  const bf16_t* kvb = (const bf16_t*)kv;
+  if (lin_b(L.sa_in, b.xb, DM, R, nullptr, 0, b.qkvb, 3 * DM, ACT_NONE, 1.f, s)) return 1;
+  if (launch_vt(b.qkvb + 2 * DM, 3 * DM, b.vts, B, Nq, NH, s)) return 1;
+  if (launch_attention_bf16(b.qkvb, 3 * DM, b.qkvb + DM, 3 * DM, b.vts, b.attb, DM, B, Nq, Nq, NH, s)) return 1;
+  if (lin_b(L.sa_out, b.attb, DM, R, b.t, DM, nullptr, 0, ACT_NONE, 1.f, s)) return 1;
+  if (style_then_ln(L.st[0], L.n1, b, R, Nq, label, n_label, n_classes, bf, s)) return 1;
+  if (lin_b(L.ca_q, b.xb, DM, R, nullptr, 0, b.qkvb, DM, ACT_NONE, 1.f, s)) return 1;
+  if (launch_attention_bf16(b.qkvb, DM, kvb, 2 * DM, vt_cross, b.attb, DM, B, Nq, Nk, NH, s)) return 1;
+  if (lin_b(L.ca_out, b.attb, DM, R, b.t, DM, nullptr, 0, ACT_NONE, 1.f, s)) return 1;
+  if (style_then_ln(L.st[1], L.n2, b, R, Nq, label, n_label, n_classes, bf, s)) return 1;
+  if (lin_b(L.ff1, b.xb, DM, R, nullptr, 0, b.hbb, FF, ACT_LEAKY, 0.f, s)) return 1;
+  if (lin_b(L.ff2, b.hbb, FF, R, b.t, DM, nullptr, 0, ACT_NONE, 1.f, s)) return 1;
+  return style_then_ln(L.st[2], L.n3, b, R, Nq, label, n_label, n_classes, bf, s);
 }
 
-static TBufs alloc_tbufs(Arena& ar, size_t R) {
+static size_t vt_elems(int B, int Nk) { return (size_t)B * NH * 64 * round_up(Nk, 32); }
+
+static TBufs alloc_tbufs(Arena& ar, size_t R, int B, int Nq, bool bf) {
   TBufs b;
   b.x = ar.f32(R * DM);
-  b.qkv = ar.f32(R * 3 * DM);
-  b.att = ar.f32(R * DM);
   b.t = ar.f32(R * DM);
-  b.hb = ar.f32(R * FF);
+  if (!bf) {
+    b.qkv = ar.f32(R * 3 * DM);
+    b.att = ar.f32(R * DM);
+    b.hb = ar.f32(R * FF);
+  } else {
+    b.xb = (bf16_t*)ar.raw(R * DM * 2);
+    b.qkvb = (bf16_t*)ar.raw(R * 3 * DM * 2);
+    b.attb = (bf16_t*)ar.raw(R * DM * 2);
+    b.hbb = (bf16_t*)ar.raw(R * FF * 2);
+    b.vts = (bf16_t*)ar.raw(vt_elems(B, Nq) * 2);
+  }
   return b;
 }
 
@@ -279,8 +342,10 @@ size_t predictor_workspace_bytes(const Model& m, int B, int T) {
   const int Tq = (T + 7) / 8;
   const size_t R = (size_t)B * Tq * P.groups;
   const size_t cond_phase = (size_t)B * T * (ld_of(P.mot_dim + 1) + 4 * 128);
-  const size_t trans = (size_t)B * Tq * (768 + DM + (size_t)P.n_layers * 2 * DM) + R * (DM * 6 + FF + P.num_codes + 1);
-  return (std::max(cond_phase + (size_t)B * Tq * 768, trans) * sizeof(float) + 64 * 256 + 255) & ~(size_t)255;
+  // fp32 sizing covers the bf16 mode too (its buffers are half as wide, plus the small V^T scratch)
+  const size_t trans = (size_t)B * Tq * (2 * 768 + DM + (size_t)P.n_layers * 3 * DM) +
+                       R * (DM * 7 + FF + P.num_codes + 1) + vt_elems(B, Tq * P.groups);
+  return (std::max(cond_phase + (size_t)B * Tq * 768, trans) * sizeof(float) + 96 * 256 + 255) & ~(size_t)255;
 }
 
 // motion-context encoder; writes channels-last condition rows [B*Tq, 768] (motion | audio)
@@ -331,32 +396,64 @@ int predictor_condition(Model& m, const float* masked_motion, const float* mask,
   return launch_cl_to_ncl(cond_cl, 768, 0, condition, B, 768, Tq, s);
 }
 
-struct PredMem { float* mem; std::vector<float*> kv; };
+struct PredMem {
+  float* mem = nullptr;                 // fp32 mode
+  bf16_t *condb = nullptr, *memb = nullptr;   // bf16 mode
+  std::vector<void*> kv;
+  std::vector<bf16_t*> vt;
+};
 
-// condition rows -> memory (condi_emb + fp64 PE) and per-layer cross-attention K|V
-static int predictor_memory(const Predictor& P, const float* cond_cl, int B, int Tq, PredMem& pm, hipStream_t s) {
+static int alloc_predmem(const Predictor& P, Arena& ar, int B, int Tq, bool bf, PredMem& pm) {
+  const size_t Rm = (size_t)B * Tq;
+  pm.kv.resize(P.n_layers);
+  pm.vt.assign(P.n_layers, nullptr);
+  if (!bf) {
+    pm.mem = ar.f32(Rm * DM);
+    for (int l = 0; l < P.n_layers; ++l) pm.kv[l] = ar.f32(Rm * 2 * DM);
+  } else {
+    pm.condb = (bf16_t*)ar.raw(Rm * 768 * 2);
+    pm.memb = (bf16_t*)ar.raw(Rm * DM * 2);
+    for (int l = 0; l < P.n_layers; ++l) {
+      pm.kv[l] = ar.raw(Rm * 2 * DM * 2);
+      pm.vt[l] = (bf16_t*)ar.raw(vt_elems(B, Tq) * 2);
+    }
+  }
+  return 0;
+}
+
+// condition rows -> memory (condi_emb + fp64 PE) and per-layer cross-attention K|V (+ V^T in bf16 mode)
+static int predictor_memory(const Predictor& P, const float* cond_cl, int B, int Tq, bool bf, PredMem& pm,
+                            hipStream_t s) {
   PT_CHECK(Tq + 1 <= P.pe_rows, "sequence of %d latent steps exceeds the positional table (%d)", Tq, P.pe_rows - 1);
-  if (lin(P.condi_emb, cond_cl, 768, B * Tq, pm.mem, DM, ACT_NONE, 1.f, s, P.pe + DM, Tq)) return 1;
-  for (int l = 0; l < P.n_layers; ++l)
-    if (lin(P.layers[l].ca_kv, pm.mem, DM, B * Tq, pm.kv[l], 2 * DM, ACT_NONE, 1.f, s)) return 1;
+  const int Rm = B * Tq;
+  if (!bf) {
+    if (lin(P.condi_emb, cond_cl, 768, Rm, pm.mem, DM, ACT_NONE, 1.f, s, P.pe + DM, Tq)) return 1;
+    for (int l = 0; l < P.n_layers; ++l)
+      if (lin(P.layers[l].ca_kv, pm.mem, DM, Rm, (float*)pm.kv[l], 2 * DM, ACT_NONE, 1.f, s)) return 1;
+    return 0;
+  }
+  if (launch_cvt_f32_bf16(cond_cl, 768, pm.condb, 768, Rm, 768, 768, s)) return 1;
+  if (lin_b(P.condi_emb, pm.condb, 768, Rm, nullptr, 0, pm.memb, DM, ACT_NONE, 1.f, s, P.pe + DM, Tq)) return 1;
+  for (int l = 0; l < P.n_layers; ++l) {
+    bf16_t* kvb = (bf16_t*)pm.kv[l];
+    if (lin_b(P.layers[l].ca_kv, pm.memb, DM, Rm, nullptr, 0, kvb, 2 * DM, ACT_NONE, 1.f, s)) return 1;
+    if (launch_vt(kvb + DM, 2 * DM, pm.vt[l], B, Tq, NH, s)) return 1;
+  }
   return 0;
 }
 
 static int predictor_pass(const Predictor& P, const int* ids, const int64_t* label, const PredMem& pm, TBufs& tb, int B,
-                          int Tq, float* logits, hipStream_t s) {
+                          int Tq, bool bf, float* logits, hipStream_t s) {
   const int N = Tq * P.groups, R = B * N;
-  if (launch_embed_pe(ids, P.tok_emb, P.pe, P.ppe, tb.x, R, N, P.groups, P.num_codes + 1, s)) return 1;
+  if (launch_embed_pe(ids, P.tok_emb, P.pe, P.ppe, tb.x, tb.xb, R, N, P.groups, P.num_codes + 1, s)) return 1;
   for (int l = 0; l < P.n_layers; ++l)
-    if (decoder_layer(P.layers[l], tb, pm.kv[l], B, N, Tq, label, B, P.n_classes, s)) return 1;
-  if (lin(P.out0, tb.x, DM, R, tb.t, DM, ACT_LEAKY, 0.f, s)) return 1;
-  return lin(P.out2, tb.t, DM, R, logits, P.num_codes, ACT_NONE, 1.f, s);
-}
-
-static int alloc_predmem(const Predictor& P, Arena& ar, int B, int Tq, PredMem& pm) {
-  pm.mem = ar.f32((size_t)B * Tq * DM);
-  pm.kv.resize(P.n_layers);
-  for (int l = 0; l < P.n_layers; ++l) pm.kv[l] = ar.f32((size_t)B * Tq * 2 * DM);
-  return 0;
+    if (decoder_layer(P.layers[l], tb, pm.kv[l], pm.vt[l], B, N, Tq, label, B, P.n_classes, bf, s)) return 1;
+  if (!bf) {
+    if (lin(P.out0, tb.x, DM, R, tb.t, DM, ACT_LEAKY, 0.f, s)) return 1;
+    return lin(P.out2, tb.t, DM, R, logits, P.num_codes, ACT_NONE, 1.f, s);
+  }
+  if (lin_b(P.out0, tb.xb, DM, R, nullptr, 0, tb.attb, DM, ACT_LEAKY, 0.f, s)) return 1;
+  return lin_b(P.out2, tb.attb, DM, R, logits, P.num_codes, nullptr, 0, ACT_NONE, 1.f, s);
 }
 
 int predictor_logits(Model& m, const int32_t* ids, const int64_t* label, const float* condition, int B, int Tq,
@@ -364,15 +461,16 @@ int predictor_logits(Model& m, const int32_t* ids, const int64_t* label, const f
   PT_CHECK(m.finalized && m.pred, "predictor_logits: wrong or unfinalized model");
   PT_CHECK(B > 0 && Tq > 0, "predictor_logits: empty input B=%d T'=%d", B, Tq);
   const Predictor& P = *m.pred;
+  const bool bf = m.precision == 1;
   Arena ar(ws, ws_bytes);
   float* cond_cl = ar.f32((size_t)B * Tq * 768);
   PredMem pm;
-  alloc_predmem(P, ar, B, Tq, pm);
-  TBufs tb = alloc_tbufs(ar, (size_t)B * Tq * P.groups);
+  alloc_predmem(P, ar, B, Tq, bf, pm);
+  TBufs tb = alloc_tbufs(ar, (size_t)B * Tq * P.groups, B, Tq * P.groups, bf);
   PT_CHECK(!ar.overflow, "predictor_logits: workspace too small (%zu given, %zu needed)", ws_bytes, ar.off);
   if (launch_ncl_to_cl(condition, cond_cl, B, 768, Tq, 768, 0, 768, s)) return 1;
-  if (predictor_memory(P, cond_cl, B, Tq, pm, s)) return 1;
-  return predictor_pass(P, ids, label, pm, tb, B, Tq, logits, s);
+  if (predictor_memory(P, cond_cl, B, Tq, bf, pm, s)) return 1;
+  return predictor_pass(P, ids, label, pm, tb, B, Tq, bf, logits, s);
 }
 
 int predictor_sample(Model& m, const int64_t* label, const float* condition, const float* noise_q, const float* noise_g,
@@ -381,22 +479,23 @@ int predictor_sample(Model& m, const int64_t* label, const float* condition, con
   PT_CHECK(m.finalized && m.pred, "predictor_sample: wrong or unfinalized model");
   PT_CHECK(B > 0 && Tq > 0 && steps > 0, "predictor_sample: empty input B=%d T'=%d steps=%d", B, Tq, steps);
   const Predictor& P = *m.pred;
+  const bool bf = m.precision == 1;
   const int N = Tq * P.groups, V = P.num_codes;
   const size_t R = (size_t)B * N;
   Arena ar(ws, ws_bytes);
   float* cond_cl = ar.f32((size_t)B * Tq * 768);
   PredMem pm;
-  alloc_predmem(P, ar, B, Tq, pm);
-  TBufs tb = alloc_tbufs(ar, R);
+  alloc_predmem(P, ar, B, Tq, bf, pm);
+  TBufs tb = alloc_tbufs(ar, R, B, N, bf);
   int* ids = (int*)ar.raw(R * sizeof(int));
   float* lg = logits_out ? nullptr : ar.f32(R * V);
   PT_CHECK(!ar.overflow, "predictor_sample: workspace too small (%zu given, %zu needed)", ws_bytes, ar.off);
   if (launch_ncl_to_cl(condition, cond_cl, B, 768, Tq, 768, 0, 768, s)) return 1;
-  if (predictor_memory(P, cond_cl, B, Tq, pm, s)) return 1;
+  if (predictor_memory(P, cond_cl, B, Tq, bf, pm, s)) return 1;
   if (launch_fill_i32(ids, V, R, s)) return 1;
   for (int t = 0; t < steps; ++t) {
     float* lt = logits_out ? logits_out + (size_t)t * R * V : lg;
-    if (predictor_pass(P, ids, label, pm, tb, B, Tq, lt, s)) return 1;
+    if (predictor_pass(P, ids, label, pm, tb, B, Tq, bf, lt, s)) return 1;
     // schedule of PTransformer.py:613-636: cosine mask ratio, fp32 product floor, annealed Gumbel temperature
     const double ratio = 1.0 * (t + 1) / steps;
     const float mask_ratio = (float)cos(ratio * M_PI / 2);
@@ -413,8 +512,9 @@ size_t refiner_workspace_bytes(const Model& m, int B, int T) {
   if (!m.ref) return 0;
   const Refiner& R = *m.ref;
   const size_t rows = (size_t)B * T;
-  const size_t f = rows * (ld_of(R.in_dim) * 2 + ld_of(R.cond_dim + 2) + DM + 2 * DM + 6 * DM + FF);
-  return (f * sizeof(float) + 32 * 256 + 255) & ~(size_t)255;
+  const size_t f = rows * (ld_of(R.in_dim) * 3 + 2 * round_up(R.cond_dim + 2, 64) + DM + 2 * DM + 7 * DM + FF) +
+                   2 * vt_elems(B, T);
+  return (f * sizeof(float) + 64 * 256 + 255) & ~(size_t)255;
 }
 
 int refiner_forward(Model& m, const float* x, const float* condition, const float* mask, const int64_t* label,
@@ -423,27 +523,54 @@ int refiner_forward(Model& m, const float* x, const float* condition, const floa
   PT_CHECK(B > 0 && T > 0, "refiner_forward: empty input B=%d T=%d", B, T);
   PT_CHECK(n_label == 1 || n_label == B, "refiner_forward: label must have 1 or B=%d entries (got %d)", B, n_label);
   const Refiner& R = *m.ref;
+  const bool bf = m.precision == 1;
   PT_CHECK(T + 1 <= R.pe_rows, "sequence of %d frames exceeds the positional table (%d)", T, R.pe_rows - 1);
-  const int rows = B * T, ldx = ld_of(R.in_dim), ldc = ld_of(R.cond_dim + 2);
+  const int rows = B * T, ldx = ld_of(R.in_dim), ldc = round_up(R.cond_dim + 2, 64);
   Arena ar(ws, ws_bytes);
   float* x_cl = ar.f32((size_t)rows * ldx);
   float* c_cl = ar.f32((size_t)rows * ldc);
-  float* mem = ar.f32((size_t)rows * DM);
-  float* kv = ar.f32((size_t)rows * 2 * DM);
-  TBufs tb = alloc_tbufs(ar, rows);
   float* o_cl = ar.f32((size_t)rows * ldx);
+  TBufs tb = alloc_tbufs(ar, rows, B, T, bf);
+  float *mem = nullptr, *kv = nullptr;
+  bf16_t *xb_cl = nullptr, *cb_cl = nullptr, *memb = nullptr, *kvb = nullptr, *vtc = nullptr, *h1b = nullptr;
+  if (!bf) {
+    mem = ar.f32((size_t)rows * DM);
+    kv = ar.f32((size_t)rows * 2 * DM);
+  } else {
+    xb_cl = (bf16_t*)ar.raw((size_t)rows * ldx * 2);
+    cb_cl = (bf16_t*)ar.raw((size_t)rows * ldc * 2);
+    memb = (bf16_t*)ar.raw((size_t)rows * DM * 2);
+    kvb = (bf16_t*)ar.raw((size_t)rows * 2 * DM * 2);
+    vtc = (bf16_t*)ar.raw(vt_elems(B, T) * 2);
+    h1b = (bf16_t*)ar.raw((size_t)rows * 1024 * 2);
+  }
   PT_CHECK(!ar.overflow, "refiner_forward: workspace too small (%zu given, %zu needed)", ws_bytes, ar.off);
   if (launch_ncl_to_cl(x, x_cl, B, R.in_dim, T, ldx, 0, ldx, s)) return 1;
   if (launch_ncl_to_cl(condition, c_cl, B, R.cond_dim, T, ldc, 0, R.cond_dim, s)) return 1;
   if (launch_mask_onehot(mask, c_cl, rows, ldc, R.cond_dim, ldc, s)) return 1;
-  if (lin(R.input_conv, x_cl, ldx, rows, tb.x, DM, ACT_NONE, 1.f, s, R.pe + DM, T)) return 1;
-  if (lin(R.audio_conv, c_cl, ldc, rows, mem, DM, ACT_NONE, 1.f, s, R.pe + DM, T)) return 1;
-  for (int l = 0; l < R.n_layers; ++l) {
-    if (lin(R.layers[l].ca_kv, mem, DM, rows, kv, 2 * DM, ACT_NONE, 1.f, s)) return 1;
-    if (decoder_layer(R.layers[l], tb, kv, B, T, T, label, n_label, R.n_classes, s)) return 1;
+  if (!bf) {
+    if (lin(R.input_conv, x_cl, ldx, rows, tb.x, DM, ACT_NONE, 1.f, s, R.pe + DM, T)) return 1;
+    if (lin(R.audio_conv, c_cl, ldc, rows, mem, DM, ACT_NONE, 1.f, s, R.pe + DM, T)) return 1;
+    for (int l = 0; l < R.n_layers; ++l) {
+      if (lin(R.layers[l].ca_kv, mem, DM, rows, kv, 2 * DM, ACT_NONE, 1.f, s)) return 1;
+      if (decoder_layer(R.layers[l], tb, kv, nullptr, B, T, T, label, n_label, R.n_classes, false, s)) return 1;
+    }
+    if (lin(R.out0, tb.x, DM, rows, tb.hb, 1024, ACT_LEAKY, 0.f, s)) return 1;
+    if (lin(R.out2, tb.hb, 1024, rows, o_cl, ldx, ACT_NONE, 1.f, s)) return 1;
+  } else {
+    if (launch_cvt_f32_bf16(x_cl, ldx, xb_cl, ldx, rows, ldx, ldx, s)) return 1;
+    if (launch_cvt_f32_bf16(c_cl, ldc, cb_cl, ldc, rows, ldc, ldc, s)) return 1;
+    if (lin_b(R.input_conv, xb_cl, ldx, rows, tb.x, DM, tb.xb, DM, ACT_NONE, 1.f, s, R.pe + DM, T)) return 1;
+    if (lin_b(R.audio_conv, cb_cl, ldc, rows, nullptr, 0, memb, DM, ACT_NONE, 1.f, s, R.pe + DM, T)) return 1;
+    for (int l = 0; l < R.n_layers; ++l) {
+      if (lin_b(R.layers[l].ca_kv, memb, DM, rows, nullptr, 0, kvb, 2 * DM, ACT_NONE, 1.f, s)) return 1;
+      if (launch_vt(kvb + DM, 2 * DM, vtc, B, T, NH, s)) return 1;
+      if (decoder_layer(R.layers[l], tb, kvb, vtc, B, T, T, label, n_label, R.n_classes, true, s)) return 1;
+    }
+    if (lin_b(R.out0, tb.xb, DM, rows, nullptr, 0, h1b, 1024, ACT_LEAKY, 0.f, s)) return 1;
+    if (lin_b(R.out2, h1b, 1024, rows, o_cl, ldx, nullptr, 0, ACT_NONE, 1.f, s)) return 1;
+    // o_cl pad columns [in_dim, ldx) stay unwritten: cl_to_ncl reads only the first in_dim columns
   }
-  if (lin(R.out0, tb.x, DM, rows, tb.hb, 1024, ACT_LEAKY, 0.f, s)) return 1;
-  if (lin(R.out2, tb.hb, 1024, rows, o_cl, ldx, ACT_NONE, 1.f, s)) return 1;
   return launch_cl_to_ncl(o_cl, ldx, 0, out, B, R.in_dim, T, s);
 }
 

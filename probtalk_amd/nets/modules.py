@@ -110,6 +110,7 @@ class _HandleOwner:
     """Lazy creation of the packed device model from the module's current state_dict."""
 
     _kind = None
+    _bf16_ok = False
 
     def _cfg(self):
         raise NotImplementedError
@@ -117,9 +118,22 @@ class _HandleOwner:
     def _handle(self):
         h = self.__dict__.get("_pt_handle")
         if h is None:
-            h = _lib.Handle(self._kind, self._cfg(), self.state_dict())
+            h = _lib.Handle(self._kind, self._cfg(), self.state_dict(),
+                            precision=self.__dict__.get("_pt_precision", "fp32"))
             self.__dict__["_pt_handle"] = h
         return h
+
+    def set_precision(self, precision):
+        """'fp32' (default, parity path) or 'bf16' (bf16 MFMA operands, fp32 accumulate/residual/LayerNorm;
+        predictor and refiner transformers only)."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        if precision == "bf16" and not self._bf16_ok:
+            raise NotImplementedError(f"{type(self).__name__} has no bf16 mode")
+        if precision != self.__dict__.get("_pt_precision", "fp32"):
+            self.__dict__["_pt_precision"] = precision
+            self.__dict__["_pt_handle"] = None
+        return self
 
     def invalidate(self):
         """Drop the packed weights (call after mutating parameters in place)."""

@@ -193,6 +193,7 @@ class PTransformer(nn.Module):
 class PredictorNet(_HandleOwner, nn.Module):
     """predictornet.py:13-112."""
     _kind = "predictor"
+    _bf16_ok = True
 
     def __init__(self, knn=False, mot_dim=256, sta_dim=2048, dim=64, enc_layers=10, ar_layers=15, n_classes=10,
                  groups=1, identity=False, maskgit=False, maskgit_T=8, transformer=False, text=False, audio=True,
@@ -270,6 +271,7 @@ class PredictorNet(_HandleOwner, nn.Module):
 class RTransformer(_HandleOwner, nn.Module):
     """RTransformer.py:181-230."""
     _kind = "refiner"
+    _bf16_ok = True
 
     def __init__(self, input_dim=512, condi_dim=512, intermediate_dim=512, num_hidden_layers=6, use_label=True,
                  n_classes=4, motion_context=False):

@@ -1,0 +1,98 @@
+"""GPU parity of the bf16 mode (BASELINE configs[2]: bf16 operands, tolerance 1e-2 relative) of the predictor and
+refiner transformers against the fp32 CPU oracle."""
+import pytest
+import torch
+
+from oracle import probtalk_oracle as O
+from probtalk_amd.weights import make_input
+from tests.helpers import golden, ref_state_dict, rel_err
+
+pytestmark = pytest.mark.gpu
+# bf16 criterion: relative error in the 2-norm, ||gpu - ref|| / ||ref|| < 1e-2 (north_star: "1e-2 in bf16"), plus a
+# guard on the worst element, max|gpu - ref| / max|ref| < 2e-2.  A CPU simulation that only rounds the GEMM operands
+# of the oracle to bf16 (no other change) gives 5.9e-3 / 8.7e-3 on the refiner fixture, i.e. this is the floor of
+# bf16 operands with these random weights, not kernel error; the fp32 path keeps the strict max-based 1e-4.
+TOL_BF16 = 1e-2
+TOL_BF16_MAX = 2e-2
+
+
+def l2_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm())
+
+
+def check_bf16(a, b, what):
+    e2, emax = l2_err(a, b), rel_err(a, b)
+    print(f"bf16 {what}: l2-rel {e2:.3e}  max-rel {emax:.3e}")
+    assert e2 < TOL_BF16 and emax < TOL_BF16_MAX, what
+
+
+def _predictor():
+    from probtalk_amd.nets.transformer_modules import PredictorNet
+    m = PredictorNet(False, 376, 128, 512, 10, 6, 4, groups=4, identity=True, maskgit=True, maskgit_T=8,
+                     transformer=True, text=None, audio="wav2vec", motion_context=True).eval()
+    m.load_state_dict(ref_state_dict("Predictor"))
+    return m.set_precision("bf16")
+
+
+def test_predictor_logits_bf16():
+    g = golden("predictor_b2_t88.npz")
+    pn = _predictor()
+    label = torch.tensor([1, 3])
+    ids = make_input("pred.ids", (2, 11, 4), "int", low=0, high=129)
+    logits = pn.decoder.tokens_to_logits(ids.cuda(), label.cuda(), g["condition"].cuda())
+    check_bf16(logits.cpu(), g["logits"], "predictor logits vs reference golden")
+    # config-3 geometry
+    sd = ref_state_dict("Predictor")
+    B, Tq = 3, 37
+    cond = make_input("bf.cond", (B, 768, Tq))
+    ids = make_input("bf.ids", (B, Tq, 4), "int", low=0, high=129)
+    lab = torch.tensor([0, 2, 3])
+    out = pn.decoder.tokens_to_logits(ids.cuda(), lab.cuda(), cond.cuda())
+    check_bf16(out.cpu(), O.tokens_to_logits(sd, ids, lab, cond), "predictor logits T'=37")
+
+
+def test_predictor_sample_bf16_runs_and_first_pass_matches():
+    g = golden("predictor_b2_t88.npz")
+    pn = _predictor()
+    label = torch.tensor([1, 3])
+    nq = make_input("pred.noise_q", (8, 2, 44, 128), "exp")
+    ng = make_input("pred.noise_g", (8, 2, 44), "gumbel")
+    codes, logits = pn.decoder.sample_good(label.cuda(), g["condition"].cuda(), None, T=8,
+                                           noise=(nq.cuda(), ng.cuda()), return_logits=True)
+    assert int(codes.min()) >= 0 and int(codes.max()) < 128
+    _, ref_logits = O.sample_good(ref_state_dict("Predictor"), label, g["condition"], nq, ng, return_logits=True)
+    check_bf16(logits[0].cpu(), ref_logits[0], "MaskGIT pass-0 logits")   # pass 0 sees the same all-mask input
+    agree = float((codes.cpu() == g["codes"]).float().mean())
+    print(f"bf16 MaskGIT codes equal to the fp32 reference run: {agree:.2%} (sampling amplifies rounding; informational)")
+
+
+def test_refiner_bf16():
+    from probtalk_amd.nets.transformer_modules import RTransformer
+    rt = RTransformer(376, 768, 512, 6, use_label=True, motion_context=True).eval()
+    rt.load_state_dict(ref_state_dict("HFTransformer"))
+    rt.set_precision("bf16")
+    g = golden("refiner_b2_t64.npz")
+    x = make_input("ref.x", (2, 376, 64))
+    aud = make_input("ref.aud", (2, 768, 64))
+    mask = torch.zeros(2, 1, 64)
+    mask[:, :, :30] = 1
+    out = rt(x.cuda(), aud.cuda(), mask.cuda(), torch.tensor([0, 2]).cuda())
+    check_bf16(out.cpu(), g["out"], "refiner vs reference golden")
+    sd = ref_state_dict("HFTransformer")
+    B, T = 2, 300
+    x3, a3 = make_input("ref.x300", (B, 376, T)), make_input("ref.a300", (B, 768, T))
+    m3 = torch.zeros(B, 1, T)
+    m3[:, :, 100:130] = 1
+    lab = torch.tensor([3])
+    check_bf16(rt(x3.cuda(), a3.cuda(), m3.cuda(), lab.cuda()).cpu(), O.rtransformer(sd, x3, a3, m3, lab),
+               "refiner T=300")
+    # switching back restores the fp32 parity path
+    rt.set_precision("fp32")
+    assert rel_err(rt(x.cuda(), aud.cuda(), mask.cuda(), torch.tensor([0, 2]).cuda()).cpu(), g["out"]) < 1e-4
+
+
+def test_bf16_mode_rejected_where_it_does_not_exist():
+    from probtalk_amd.nets.modules import VQVAE_SC
+    with pytest.raises(NotImplementedError):
+        VQVAE_SC(376, 512, 128, 1024, 2, 512, q_type="pro", groups=4).set_precision("bf16")
