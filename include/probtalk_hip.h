@@ -111,6 +111,10 @@ int pt_cl_to_ncl(const float* in, int ldi, float* out, int B, int C, int L, void
 int pt_pq_search_cl(const float* z, int ldz, const float* codebooks, int rows, int G, int D, int K, int64_t* idx,
                     float* q, int ldq, void* stream);
 
+/* bf16-operand Linear: C[M,N] (fp32) and/or Cb[M,N] (bf16) = act(A[M,K] . W[N,K]^T + bias); A, W bf16 bit patterns,
+ * W rows padded to Npad (multiple of 128), K a multiple of 64 (nn.Linear / 1x1 conv of the bf16 mode). */
+int pt_gemm_bf16(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, int Npad, float* C,
+                 int ldc, void* Cb, int ldcb, int relu, void* stream);
 /* softmax(Q K^T / 8) V per (clip, head), head dim 64 (nn.MultiheadAttention core, PTransformer.py:340-353):
  * Q rows b*Nq+i at Q + row*ldq + head*64; K/V rows b*Nk+j likewise; O like Q. */
 int pt_attention_cl(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,

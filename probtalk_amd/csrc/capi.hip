@@ -196,6 +196,18 @@ int pt_prof_read(double* ms6, double* flops6, int* launches6) {
   PT_CHECK(ms6 && flops6 && launches6, "pt_prof_read: null argument");
   return prof_read(ms6, flops6, launches6);
 }
+int pt_gemm_bf16(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, int Npad, float* C,
+                 int ldc, void* Cb, int ldcb, int relu, void* stream) {
+  PT_CHECK(A && W && (C || Cb), "pt_gemm_bf16: null argument");
+  GemmArgsB a;
+  memset(&a, 0, sizeof(a));
+  a.A = (const unsigned short*)A; a.lda = lda; a.W = (const unsigned short*)W; a.bias = bias;
+  a.C = C; a.ldc = ldc; a.Cb = (unsigned short*)Cb; a.ldcb = ldcb;
+  a.M = M; a.N = N; a.K = K; a.Npad = Npad; a.ntaps = 1;
+  a.Lgrid = M; a.Lin = M; a.Lout = M; a.in_stride = 1; a.out_stride = 1;
+  a.act = relu ? ACT_LEAKY : ACT_NONE; a.slope = 0.f;
+  return launch_gemm_bf16(a, (hipStream_t)stream);
+}
 int pt_attention_cl(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,
                     int Nq, int Nk, int H, void* stream) {
   PT_CHECK(Q && K && V && O, "pt_attention_cl: null argument");
