@@ -66,7 +66,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="clips per step per GPU (micro-batch of configs[3])")
+    ap.add_argument("--batch", type=int, default=512,
+                    help="clips per step per GPU: the per-GPU share of configs[3] (4096 clips over 8 GPUs), one batch")
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--dtype", choices=("bf16", "f32"), default="bf16",
                     help="arithmetic of the predictor/refiner transformers (conv stacks and PQ stay fp32)")
@@ -143,13 +144,14 @@ def main():
         _lib.check(L.pt_prof_enable(1))
         holistic_step(pred, ref, aud, gt, mask, ids, sync=False)
         torch.cuda.synchronize()
-        ms, fl, ln = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_int * 6)()
+        ms, fl, ln = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int * 8)()
         _lib.check(L.pt_prof_read(ms, fl, ln))
         _lib.check(L.pt_prof_enable(0))
-        names = ("f32 128x128", "f32 64x128", "f32 64x64", "bf16 128x128", "bf16 64x128", "bf16 64x64")
-        dom = range(3, 6) if a.dtype == "bf16" else range(0, 3)     # the dominant kernel family of this mode
+        names = ("f32 128x128", "f32 64x128", "f32 64x64", "bf16 128x128", "bf16 64x128", "bf16 64x64",
+                 "bf16 256x256 lds-dma", "bf16 128x512 lds-dma +LN epilogues")
+        dom = range(3, 8) if a.dtype == "bf16" else range(0, 3)     # the dominant kernel family of this mode
         peak = PEAK_BF16_MFMA_TFLOPS if a.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-        kname = "pt::gemm_bf16_kernel (tap-GEMM, bf16 MFMA 32x32x16)" if a.dtype == "bf16" else \
+        kname = "pt::gemm_big_kernel + pt::gemm_bf16_kernel (bf16 MFMA 32x32x16 GEMMs of the transformers)" if a.dtype == "bf16" else \
             "pt::gemm_f32_kernel (tap-GEMM, fp32 MFMA 32x32x2)"
         tot_ms, tot_fl, tot_n = sum(ms[i] for i in dom), sum(fl[i] for i in dom), sum(ln[i] for i in dom)
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
@@ -162,7 +164,7 @@ def main():
             "kernel_ms_per_step": tot_ms,
             "per_kernel_config": {names[i]: {"launches": ln[i], "ms": ms[i], "gflop": fl[i] / 1e9,
                                              "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] else 0.0}
-                                  for i in range(6) if ln[i]},
+                                  for i in range(8) if ln[i]},
             "whole_step": {"algorithmic_tflop": step_tflop,
                            "achieved_tflops": step_tflop / (1e-3 * res["ms_per_step"])},
         }

@@ -112,18 +112,30 @@ int pt_pq_search_cl(const float* z, int ldz, const float* codebooks, int rows, i
                     float* q, int ldq, void* stream);
 
 /* bf16-operand Linear: C[M,N] (fp32) and/or Cb[M,N] (bf16) = act(A[M,K] . W[N,K]^T + bias); A, W bf16 bit patterns,
- * W rows padded to Npad (multiple of 128), K a multiple of 64 (nn.Linear / 1x1 conv of the bf16 mode). */
+ * W rows padded to Npad (multiple of 128), K a multiple of 64 (nn.Linear / 1x1 conv of the bf16 mode).
+ * N >= 256 runs on the large-tile LDS-DMA kernel, narrower outputs on the 4-wave tap-GEMM. */
 int pt_gemm_bf16(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, int Npad, float* C,
                  int ldc, void* Cb, int ldcb, int relu, void* stream);
+/* Linear to d_model = 512 with the stylization pre-op fused (DeepSupervisionLayer sub-layer output -> StylizationBlock,
+ * PTransformer.py:134-139): out_bf16[M,512] = SiLU(LN(A.W^T + bias; gamma, beta) * (1 + style[c][0:512]) + style[c][512:1024]),
+ * c = label[row / rows_per_clip] (label[0] when n_label == 1); style is [n_classes][1024] fp32. */
+int pt_gemm_bf16_lnmod(const void* A, int lda, const void* W, const float* bias, int M, int K, int Npad,
+                       const float* gamma, const float* beta, const float* style, const int64_t* label, int n_label,
+                       int rows_per_clip, int n_classes, void* out_bf16, void* stream);
+/* Linear to d_model = 512 with the post-LN residual fused (PTransformer.py:329-331):
+ * x[M,512] = LN(x + A.W^T + bias; gamma, beta) in place (fp32), x_bf16 = its bf16 copy. */
+int pt_gemm_bf16_addln(const void* A, int lda, const void* W, const float* bias, int M, int K, int Npad,
+                       const float* gamma, const float* beta, float* x, void* x_bf16, void* stream);
 /* softmax(Q K^T / 8) V per (clip, head), head dim 64 (nn.MultiheadAttention core, PTransformer.py:340-353):
  * Q rows b*Nq+i at Q + row*ldq + head*64; K/V rows b*Nk+j likewise; O like Q. */
 int pt_attention_cl(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,
                     int Nq, int Nk, int H, void* stream);
 /* measurement aid (bench.py roofline leg): when enabled every tap-GEMM launch is bracketed by HIP events
  * on its stream; pt_prof_read sums elapsed ms / algorithmic FLOPs / launches per kernel config
- * {fp32 128x128, 64x128, 64x64, bf16 128x128, 64x128, 64x64} (arrays of 6); call it after synchronising. */
+ * {fp32 128x128, 64x128, 64x64, bf16 128x128, 64x128, 64x64, bf16 256x256, bf16 128x512} (arrays of 8);
+ * call it after synchronising. */
 int pt_prof_enable(int on);
-int pt_prof_read(double* ms6, double* flops6, int* launches6);
+int pt_prof_read(double* ms8, double* flops8, int* launches8);
 /* code gather on raw buffers: idx (rows,G) int32/int64, codebooks [G][K][D] -> out [rows, ldq] (quantize_all). */
 int pt_pq_gather_cl(const void* idx, int idx_are_int64, const float* codebooks, int rows, int G, int D, int K,
                     float* out, int ldq, void* stream);

@@ -51,6 +51,8 @@ def _proto(lib):
     lib.pt_prof_enable.argtypes = [i]
     lib.pt_prof_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.pt_gemm_bf16.argtypes = [vp, i, vp, vp, i, i, i, i, vp, i, vp, i, i, vp]
+    lib.pt_gemm_bf16_lnmod.argtypes = [vp, i, vp, vp, i, i, i, vp, vp, vp, vp, i, i, i, vp, vp]
+    lib.pt_gemm_bf16_addln.argtypes = [vp, i, vp, vp, i, i, i, vp, vp, vp, vp, vp]
     lib.pt_attention_cl.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
@@ -65,7 +67,8 @@ EXPORTS = [
     "pt_pq_quantize_all", "pt_cond_encoder_workspace_bytes", "pt_cond_encoder_forward",
     "pt_predictor_workspace_bytes", "pt_predictor_condition", "pt_predictor_logits", "pt_predictor_sample",
     "pt_refiner_workspace_bytes", "pt_refiner_forward", "pt_interp_blend", "pt_conv1d_cl", "pt_ncl_to_cl",
-    "pt_cl_to_ncl", "pt_pq_search_cl", "pt_pq_gather_cl", "pt_attention_cl", "pt_gemm_bf16", "pt_prof_enable",
+    "pt_cl_to_ncl", "pt_pq_search_cl", "pt_pq_gather_cl", "pt_attention_cl", "pt_gemm_bf16", "pt_gemm_bf16_lnmod",
+    "pt_gemm_bf16_addln", "pt_prof_enable",
     "pt_prof_read",
 ]
 

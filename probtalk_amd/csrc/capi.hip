@@ -192,13 +192,21 @@ int pt_prof_enable(int on) {
   prof_enable(on != 0);
   return 0;
 }
-int pt_prof_read(double* ms6, double* flops6, int* launches6) {
-  PT_CHECK(ms6 && flops6 && launches6, "pt_prof_read: null argument");
-  return prof_read(ms6, flops6, launches6);
+int pt_prof_read(double* ms8, double* flops8, int* launches8) {
+  PT_CHECK(ms8 && flops8 && launches8, "pt_prof_read: null argument");
+  return prof_read(ms8, flops8, launches8);
 }
 int pt_gemm_bf16(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, int Npad, float* C,
                  int ldc, void* Cb, int ldcb, int relu, void* stream) {
   PT_CHECK(A && W && (C || Cb), "pt_gemm_bf16: null argument");
+  if (N >= 256 && N % 4 == 0) {   // same dispatch as the transformer sequences (transformer.hip lin_b)
+    GemmBigArgs b;
+    memset(&b, 0, sizeof(b));
+    b.A = (const unsigned short*)A; b.lda = lda; b.W = (const unsigned short*)W; b.bias = bias;
+    b.M = M; b.N = N; b.K = K; b.Npad = Npad; b.epi = EPI_STD;
+    b.C = C; b.ldc = ldc; b.Cb = (unsigned short*)Cb; b.ldcb = ldcb; b.relu = relu;
+    return launch_gemm_big(b, (hipStream_t)stream);
+  }
   GemmArgsB a;
   memset(&a, 0, sizeof(a));
   a.A = (const unsigned short*)A; a.lda = lda; a.W = (const unsigned short*)W; a.bias = bias;
@@ -207,6 +215,28 @@ int pt_gemm_bf16(const void* A, int lda, const void* W, const float* bias, int M
   a.Lgrid = M; a.Lin = M; a.Lout = M; a.in_stride = 1; a.out_stride = 1;
   a.act = relu ? ACT_LEAKY : ACT_NONE; a.slope = 0.f;
   return launch_gemm_bf16(a, (hipStream_t)stream);
+}
+int pt_gemm_bf16_lnmod(const void* A, int lda, const void* W, const float* bias, int M, int K, int Npad,
+                       const float* gamma, const float* beta, const float* style, const int64_t* label, int n_label,
+                       int rows_per_clip, int n_classes, void* out_bf16, void* stream) {
+  PT_CHECK(A && W && out_bf16, "pt_gemm_bf16_lnmod: null argument");
+  GemmBigArgs b;
+  memset(&b, 0, sizeof(b));
+  b.A = (const unsigned short*)A; b.lda = lda; b.W = (const unsigned short*)W; b.bias = bias;
+  b.M = M; b.N = 512; b.K = K; b.Npad = Npad; b.epi = EPI_LNMOD;
+  b.Cb = (unsigned short*)out_bf16; b.ldcb = 512; b.gamma = gamma; b.beta = beta; b.style = style;
+  b.label = label; b.n_label = n_label; b.rows_per_clip = rows_per_clip; b.n_classes = n_classes;
+  return launch_gemm_big(b, (hipStream_t)stream);
+}
+int pt_gemm_bf16_addln(const void* A, int lda, const void* W, const float* bias, int M, int K, int Npad,
+                       const float* gamma, const float* beta, float* x, void* x_bf16, void* stream) {
+  PT_CHECK(A && W && x && x_bf16, "pt_gemm_bf16_addln: null argument");
+  GemmBigArgs b;
+  memset(&b, 0, sizeof(b));
+  b.A = (const unsigned short*)A; b.lda = lda; b.W = (const unsigned short*)W; b.bias = bias;
+  b.M = M; b.N = 512; b.K = K; b.Npad = Npad; b.epi = EPI_ADDLN;
+  b.Cb = (unsigned short*)x_bf16; b.ldcb = 512; b.gamma = gamma; b.beta = beta; b.X = x;
+  return launch_gemm_big(b, (hipStream_t)stream);
 }
 int pt_attention_cl(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,
                     int Nq, int Nk, int H, void* stream) {

@@ -68,7 +68,7 @@ struct GemmArgs {
   double flops;                  // algorithmic FLOPs of this launch (profiling only; 0 = 2*M*N*K*taps)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
-constexpr int PROF_CFGS = 6;
+constexpr int PROF_CFGS = 8;
 void prof_enable(bool on);
 int prof_read(double* ms, double* flops, int* launches);
 
@@ -93,6 +93,30 @@ struct GemmArgsB {
   double flops;
 };
 int launch_gemm_bf16(const GemmArgsB& a, hipStream_t s);
+
+// Large-tile bf16 Linear (gemm_bf16_big.hip): 256x256 tiles, or 128x512 tiles that own whole d_model=512
+// rows and can fuse the LayerNorm that follows the Linear in the decoder layer.
+enum Epi { EPI_STD = 0, EPI_LNMOD = 1, EPI_ADDLN = 2 };
+struct GemmBigArgs {
+  const unsigned short* A; int lda;   // [M, lda] bf16
+  const unsigned short* W;            // [Npad, K] bf16
+  const float* bias;                  // [N]
+  int M, N, K, Npad;
+  int epi;
+  // EPI_STD: C fp32 and/or Cb bf16 = act(A.W^T + bias (+pe fp64) (+Res))
+  float* C; int ldc;
+  unsigned short* Cb; int ldcb;       // bf16 output (all epilogues)
+  const float* Res; int ldr;
+  const double* pe; int pe_period;
+  int relu, zero_to;
+  // EPI_LNMOD: Cb = SiLU(LN(acc+bias; gamma,beta) * (1 + style[label][0:512]) + style[label][512:1024])
+  // EPI_ADDLN: X = LN(X + acc + bias; gamma,beta) in place (fp32), Cb = bf16 copy
+  const float* gamma; const float* beta;
+  const float* style; const int64_t* label; int n_label, rows_per_clip, n_classes;
+  float* X;
+  double flops;
+};
+int launch_gemm_big(const GemmBigArgs& a, hipStream_t s);
 
 // layout
 int launch_ncl_to_cl(const float* in, float* out, int B, int C, int L, int ldo, int col_off, int zero_to, hipStream_t s);

@@ -245,11 +245,21 @@ static inline int lin(const DevConv& c, const float* A, int lda, int rows, float
   return run_conv(c, CONV_K1, A, lda, 1, rows, C, ldc, act, slope, nullptr, 0, s, nullptr, -1, pe, period);
 }
 
-// bf16-operand Linear: A bf16 [rows, lda] -> C fp32 and/or Cb bf16
+// bf16-operand Linear: A bf16 [rows, lda] -> C fp32 and/or Cb bf16.  N >= 256 goes to the large-tile
+// LDS-DMA kernel (gemm_bf16_big.hip), narrow heads to the 4-wave tap-GEMM.
 static int lin_b(const DevConv& c, const bf16_t* A, int lda, int rows, float* C, int ldc, bf16_t* Cb, int ldcb, int act,
                  float slope, hipStream_t s, const double* pe = nullptr, int period = 0) {
   PT_CHECK(c.wb != nullptr, "bf16 weights were not packed for this layer");
   PT_CHECK(lda >= c.Kb, "lin_b: input leading dim %d < packed K %d", lda, c.Kb);
+  if (c.N >= 256 && c.N % 4 == 0 && (act == ACT_NONE || slope == 0.f)) {
+    GemmBigArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.W = c.wb; a.bias = c.b; a.M = rows; a.N = c.N; a.K = c.Kb; a.Npad = c.Npad;
+    a.epi = EPI_STD; a.C = C; a.ldc = ldc; a.Cb = Cb; a.ldcb = ldcb; a.pe = pe; a.pe_period = period;
+    a.relu = act == ACT_LEAKY;
+    a.flops = 2.0 * rows * c.N * c.Cin;
+    return launch_gemm_big(a, s);
+  }
   GemmArgsB a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.W = c.wb; a.bias = c.b; a.C = C; a.ldc = ldc; a.Cb = Cb; a.ldcb = ldcb;
@@ -262,19 +272,34 @@ static int lin_b(const DevConv& c, const bf16_t* A, int lda, int rows, float* C,
   return launch_gemm_bf16(a, s);
 }
 
+// bf16 mode, tail of every sub-layer: the sub-layer's last Linear `last` (A -> 512) with the style pre-op fused into
+// its epilogue (tmp = SiLU(LN(.)(1+scale)+shift), bf16), then the style Linear with the post-LN residual fused
+// (x = LN(x + .), fp32 + bf16 copy).  The pre-LayerNorm activations never reach HBM.
+static int sublayer_tail_b(const DevConv& last, const bf16_t* A, int lda, bf16_t* tmp, const StyleW& st, const LNW& ln,
+                           float* x, bf16_t* xb, int rows, int rows_per_clip, const int64_t* label, int n_label,
+                           int n_classes, hipStream_t s) {
+  PT_CHECK(last.wb && st.out.wb && last.N == DM && st.out.N == DM && st.out.Kb == DM, "sublayer_tail: unexpected geometry");
+  GemmBigArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.W = last.wb; a.bias = last.b; a.M = rows; a.N = DM; a.K = last.Kb; a.Npad = last.Npad;
+  a.epi = EPI_LNMOD; a.Cb = tmp; a.ldcb = DM; a.gamma = st.ln.g; a.beta = st.ln.b; a.style = st.table;
+  a.label = label; a.n_label = n_label; a.rows_per_clip = rows_per_clip; a.n_classes = n_classes;
+  a.flops = 2.0 * rows * DM * last.Cin;
+  if (launch_gemm_big(a, s)) return 1;
+  memset(&a, 0, sizeof(a));
+  a.A = tmp; a.lda = DM; a.W = st.out.wb; a.bias = st.out.b; a.M = rows; a.N = DM; a.K = DM; a.Npad = st.out.Npad;
+  a.epi = EPI_ADDLN; a.X = x; a.Cb = xb; a.ldcb = DM; a.gamma = ln.g; a.beta = ln.b;
+  a.flops = 2.0 * rows * DM * DM;
+  return launch_gemm_big(a, s);
+}
+
 static int style_then_ln(const StyleW& st, const LNW& ln, TBufs& b, int rows, int rows_per_clip, const int64_t* label,
-                         int n_label, int n_classes, bool bf, hipStream_t s) {
-  // b.t holds the sub-layer output; x <- LN(x + style(t))
-  if (!bf) {
-    if (launch_ln_mod_silu(b.t, b.att, nullptr, st.ln.g, st.ln.b, st.table, label, n_label, rows, rows_per_clip,
-                           n_classes, s)) return 1;
-    if (lin(st.out, b.att, DM, rows, b.t, DM, ACT_NONE, 1.f, s)) return 1;
-    return launch_add_ln(b.x, b.t, ln.g, ln.b, rows, nullptr, s);
-  }
-  if (launch_ln_mod_silu(b.t, nullptr, b.attb, st.ln.g, st.ln.b, st.table, label, n_label, rows, rows_per_clip,
+                         int n_label, int n_classes, hipStream_t s) {
+  // fp32 mode: b.t holds the sub-layer output; x <- LN(x + style(t))
+  if (launch_ln_mod_silu(b.t, b.att, nullptr, st.ln.g, st.ln.b, st.table, label, n_label, rows, rows_per_clip,
                          n_classes, s)) return 1;
-  if (lin_b(st.out, b.attb, DM, rows, b.t, DM, nullptr, 0, ACT_NONE, 1.f, s)) return 1;
-  return launch_add_ln(b.x, b.t, ln.g, ln.b, rows, b.xb, s);
+  if (lin(st.out, b.att, DM, rows, b.t, DM, ACT_NONE, 1.f, s)) return 1;
+  return launch_add_ln(b.x, b.t, ln.g, ln.b, rows, nullptr, s);
 }
 
 // kv: fp32 mode [Rm, 1024] floats (K | V); bf16 mode the same in bf16 plus vt_cross = V^T per head
@@ -286,28 +311,25 @@ static int decoder_layer(const DecLayer& L, TBufs& b, const void* kv, const bf16
     if (lin(L.sa_in, b.x, DM, R, b.qkv, 3 * DM, ACT_NONE, 1.f, s)) return 1;
     if (launch_attention(b.qkv, 3 * DM, b.qkv + DM, 3 * DM, b.qkv + 2 * DM, 3 * DM, b.att, DM, B, Nq, Nq, NH, s)) return 1;
     if (lin(L.sa_out, b.att, DM, R, b.t, DM, ACT_NONE, 1.f, s)) return 1;
-    if (style_then_ln(L.st[0], L.n1, b, R, Nq, label, n_label, n_classes, bf, s)) return 1;
+    if (style_then_ln(L.st[0], L.n1, b, R, Nq, label, n_label, n_classes, s)) return 1;
     if (lin(L.ca_q, b.x, DM, R, b.qkv, DM, ACT_NONE, 1.f, s)) return 1;
     if (launch_attention(b.qkv, DM, kvf, 2 * DM, kvf + DM, 2 * DM, b.att, DM, B, Nq, Nk, NH, s)) return 1;
     if (lin(L.ca_out, b.att, DM, R, b.t, DM, ACT_NONE, 1.f, s)) return 1;
-    if (style_then_ln(L.st[1], L.n2, b, R, Nq, label, n_label, n_classes, bf, s)) return 1;
+    if (style_then_ln(L.st[1], L.n2, b, R, Nq, label, n_label, n_classes, s)) return 1;
     if (lin(L.ff1, b.x, DM, R, b.hb, FF, ACT_LEAKY, 0.f, s)) return 1;
     if (lin(L.ff2, b.hb, FF, R, b.t, DM, ACT_NONE, 1.f, s)) return 1;
-    return style_then_ln(L.st[2], L.n3, b, R, Nq, label, n_label, n_classes, bf, s);
+    return style_then_ln(L.st[2], L.n3, b, R, Nq, label, n_label, n_classes, s);
   }
   const bf16_t* kvb = (const bf16_t*)kv;
   if (lin_b(L.sa_in, b.xb, DM, R, nullptr, 0, b.qkvb, 3 * DM, ACT_NONE, 1.f, s)) return 1;
   if (launch_vt(b.qkvb + 2 * DM, 3 * DM, b.vts, B, Nq, NH, s)) return 1;
   if (launch_attention_bf16(b.qkvb, 3 * DM, b.qkvb + DM, 3 * DM, b.vts, b.attb, DM, B, Nq, Nq, NH, s)) return 1;
-  if (lin_b(L.sa_out, b.attb, DM, R, b.t, DM, nullptr, 0, ACT_NONE, 1.f, s)) return 1;
-  if (style_then_ln(L.st[0], L.n1, b, R, Nq, label, n_label, n_classes, bf, s)) return 1;
+  if (sublayer_tail_b(L.sa_out, b.attb, DM, b.hbb, L.st[0], L.n1, b.x, b.xb, R, Nq, label, n_label, n_classes, s)) return 1;
   if (lin_b(L.ca_q, b.xb, DM, R, nullptr, 0, b.qkvb, DM, ACT_NONE, 1.f, s)) return 1;
   if (launch_attention_bf16(b.qkvb, DM, kvb, 2 * DM, vt_cross, b.attb, DM, B, Nq, Nk, NH, s)) return 1;
-  if (lin_b(L.ca_out, b.attb, DM, R, b.t, DM, nullptr, 0, ACT_NONE, 1.f, s)) return 1;
-  if (style_then_ln(L.st[1], L.n2, b, R, Nq, label, n_label, n_classes, bf, s)) return 1;
+  if (sublayer_tail_b(L.ca_out, b.attb, DM, b.hbb, L.st[1], L.n2, b.x, b.xb, R, Nq, label, n_label, n_classes, s)) return 1;
   if (lin_b(L.ff1, b.xb, DM, R, nullptr, 0, b.hbb, FF, ACT_LEAKY, 0.f, s)) return 1;
-  if (lin_b(L.ff2, b.hbb, FF, R, b.t, DM, nullptr, 0, ACT_NONE, 1.f, s)) return 1;
-  return style_then_ln(L.st[2], L.n3, b, R, Nq, label, n_label, n_classes, bf, s);
+  return sublayer_tail_b(L.ff2, b.hbb, FF, b.attb, L.st[2], L.n3, b.x, b.xb, R, Nq, label, n_label, n_classes, s);
 }
 
 static size_t vt_elems(int B, int Nk) { return (size_t)B * NH * 64 * round_up(Nk, 32); }

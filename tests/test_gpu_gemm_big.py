@@ -1,0 +1,105 @@
+"""GPU tests of the large-tile bf16 GEMM (gemm_bf16_big.hip) through the C ABI: plain epilogue and the two fused
+LayerNorm epilogues, against a float64 PyTorch reference fed the SAME bf16-rounded operands (so only accumulation
+order and the bf16 rounding of the output differ)."""
+import pytest
+import torch
+
+from probtalk_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(M, N, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    Np = (N + 127) // 128 * 128
+    A = torch.randn(M, K, generator=g).bfloat16()
+    W = (torch.randn(Np, K, generator=g) * K ** -0.5).bfloat16()
+    bias = torch.randn(Np, generator=g)
+    return A, W, bias, Np
+
+
+def _ln(v, g, b):
+    mu = v.mean(-1, keepdim=True)
+    var = ((v - mu) ** 2).mean(-1, keepdim=True)
+    return (v - mu) / torch.sqrt(var + 1e-5) * g + b
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(300, 512, 512, 0), (1000, 1536, 512, 0), (777, 2048, 512, 1),
+                                        (513, 512, 2048, 0), (260, 376, 1024, 0), (4096, 1024, 832, 1)])
+def test_big_gemm_plain(M, N, K, relu):
+    L = _lib.lib()
+    A, W, bias, Np = _mk(M, N, K, 1 + M)
+    ref = A.double() @ W[:N].double().t() + bias[:N].double()
+    if relu:
+        ref = ref.clamp_min(0)
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    ldc = N + 8
+    C = torch.full((M, ldc), 7.0, device="cuda")
+    Cb = torch.full((M, ldc), 7.0, device="cuda", dtype=torch.bfloat16)
+    _lib.check(L.pt_gemm_bf16(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, N, K, Np, _lib.ptr(C), ldc,
+                              _lib.ptr(Cb), ldc, relu, _lib.stream()))
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    assert float((C[:, :N].cpu().double() - ref).abs().max()) / scale < 2e-6
+    assert float((Cb[:, :N].cpu().double() - ref).abs().max()) / scale < 5e-3          # one bf16 rounding
+    assert bool((C[:, N:] == 7.0).all()) and bool((Cb[:, N:] == 7.0).all())            # nothing outside [0, N)
+
+
+@pytest.mark.parametrize("M,K", [(148 * 3, 512), (300 * 2 + 17, 2048)])
+def test_big_gemm_lnmod(M, K):
+    L = _lib.lib()
+    A, W, bias, Np = _mk(M, 512, K, 11)
+    g = torch.Generator().manual_seed(5)
+    gamma, beta = 1 + 0.3 * torch.randn(512, generator=g), 0.2 * torch.randn(512, generator=g)
+    style = 0.5 * torch.randn(4, 1024, generator=g)
+    rpc = 148
+    nclip = (M + rpc - 1) // rpc
+    label = torch.randint(0, 4, (nclip,), generator=g)
+    v = A.double() @ W[:512].double().t() + bias[:512].double()
+    lab_row = label[torch.arange(M) // rpc]
+    y = _ln(v, gamma.double(), beta.double()) * (1 + style[lab_row, :512].double()) + style[lab_row, 512:].double()
+    ref = y * torch.sigmoid(y)
+    out = torch.zeros(M, 512, device="cuda", dtype=torch.bfloat16)
+    Ad, Wd, bd, gd, btd, sd, ld = (t.cuda() for t in (A, W, bias, gamma, beta, style, label))   # keep them alive
+    _lib.check(L.pt_gemm_bf16_lnmod(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, K, Np, _lib.ptr(gd), _lib.ptr(btd),
+                                    _lib.ptr(sd), _lib.ptr(ld), nclip, rpc, 4, _lib.ptr(out), _lib.stream()))
+    torch.cuda.synchronize()
+    assert float((out.cpu().double() - ref).abs().max()) / float(ref.abs().max()) < 5e-3
+    # a single label applies to every row
+    out1 = torch.zeros(M, 512, device="cuda", dtype=torch.bfloat16)
+    one = torch.tensor([2]).cuda()
+    _lib.check(L.pt_gemm_bf16_lnmod(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, K, Np, _lib.ptr(gd), _lib.ptr(btd),
+                                    _lib.ptr(sd), _lib.ptr(one), 1, rpc, 4, _lib.ptr(out1), _lib.stream()))
+    torch.cuda.synchronize()
+    y1 = _ln(v, gamma.double(), beta.double()) * (1 + style[2, :512].double()) + style[2, 512:].double()
+    ref1 = y1 * torch.sigmoid(y1)
+    assert float((out1.cpu().double() - ref1).abs().max()) / float(ref1.abs().max()) < 5e-3
+
+
+@pytest.mark.parametrize("M,K", [(148 * 2 + 5, 512), (1024, 512)])
+def test_big_gemm_addln(M, K):
+    L = _lib.lib()
+    A, W, bias, Np = _mk(M, 512, K, 23)
+    g = torch.Generator().manual_seed(9)
+    gamma, beta = 1 + 0.3 * torch.randn(512, generator=g), 0.2 * torch.randn(512, generator=g)
+    x = torch.randn(M, 512, generator=g)
+    ref = _ln(x.double() + A.double() @ W[:512].double().t() + bias[:512].double(), gamma.double(), beta.double())
+    xd = x.cuda()
+    xb = torch.zeros(M, 512, device="cuda", dtype=torch.bfloat16)
+    Ad, Wd, bd, gd, btd = (t.cuda() for t in (A, W, bias, gamma, beta))   # keep them alive
+    _lib.check(L.pt_gemm_bf16_addln(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, K, Np, _lib.ptr(gd), _lib.ptr(btd),
+                                    _lib.ptr(xd), _lib.ptr(xb), _lib.stream()))
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    assert float((xd.cpu().double() - ref).abs().max()) / scale < 5e-6
+    assert float((xb.cpu().double() - ref).abs().max()) / scale < 5e-3
+
+
+def test_big_gemm_rejects_bad_geometry():
+    L = _lib.lib()
+    A = torch.zeros(64, 96, device="cuda", dtype=torch.bfloat16)
+    W = torch.zeros(512, 96, device="cuda", dtype=torch.bfloat16)
+    C = torch.zeros(64, 512, device="cuda")
+    rc = L.pt_gemm_bf16(_lib.ptr(A), 96, _lib.ptr(W), None, 64, 512, 96, 512, _lib.ptr(C), 512, None, 0, 0,
+                        _lib.stream())
+    assert rc != 0 and b"multiple of 64" in L.pt_last_error()
