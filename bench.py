@@ -89,8 +89,8 @@ def main():
 
     pred, ref = build_pipeline(seed=0)
     if a.dtype == "bf16":
-        pred.Predictor.set_precision("bf16")
-        ref.RTransformer.set_precision("bf16")
+        for mod in (pred.Predictor, pred.AudEnc, pred.VQ, ref.RTransformer):
+            mod.set_precision("bf16")
     B, T = a.batch, a.frames
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     aud = torch.randn(B, 768, T, device=dev, generator=g)          # wav2vec2-base feature shape (768-d, 30 fps)
@@ -133,7 +133,7 @@ def main():
         "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": "configs[3] per-GPU share: full holistic pipeline (AudEnc + motion-context encoder + "
                                "8-pass MaskGIT predictor + PQ gather/decode + refiner); "
-                               + ("transformers bf16 MFMA / fp32 accumulate, conv stacks fp32" if a.dtype == "bf16" else "fp32"),
+                               + ("bf16 MFMA operands / fp32 accumulate in the transformers, condition encoders and PQ-VAE decoder" if a.dtype == "bf16" else "fp32"),
                    "clips_per_step_per_gpu": B, "frames_per_clip": T,
                    "parallelism": f"dp{world}: clips sharded over ranks, outputs all_gathered over RCCL"},
     }

@@ -37,9 +37,10 @@ pt_model* pt_model_create(const char* kind, const int* cfg, int ncfg);
  * i.e. what `module.state_dict()` / a ckpt-*.pth holds (vq_teacher.py:103-114, predictor.py:128-143).
  * dtype: 0 = float32, 1 = float64 (positional-encoding tables). */
 int pt_model_set_tensor(pt_model* m, const char* name, const void* host_data, const int64_t* shape, int ndim, int dtype);
-/* Arithmetic of the transformer GEMMs / attention: 0 = fp32 (default; parity path, 1e-4), 1 = bf16 operands with
- * fp32 accumulation, fp32 residual stream and LayerNorm (BASELINE configs[2]; tolerance 1e-2).  Predictor and
- * refiner only; call before pt_model_finalize. */
+/* Arithmetic: 0 = fp32 (default; parity path, 1e-4), 1 = bf16 MFMA operands with fp32 accumulation (BASELINE configs[2];
+ * tolerance 1e-2): predictor / refiner transformers (fp32 residual stream and LayerNorm), the motion-context and audio
+ * condition encoders, and the PQ-VAE DECODER.  PQ-VAE encode + nearest-code search always run in fp32 (bit-exact
+ * indices).  Not available for "vqvae_legacy".  Call before pt_model_finalize. */
 int pt_model_set_precision(pt_model* m, int precision);
 /* Fold BatchNorm(eval) into the convs, repack, upload.  Replaces nn.Module.load_state_dict + .to(device). */
 int pt_model_finalize(pt_model* m);

@@ -1,12 +1,5 @@
-// bf16-mode helpers of the transformer path: fp32->bf16 row conversion, the per-head V transpose and
-// the attention core on v_mfma_f32_32x32x16_bf16.
-//
-// Attention uses the same "swapped" formulation as attention.hip: S^T = K Q^T puts one query per lane
-// column, so softmax is in-register and the fp32 probabilities, packed pairwise to bf16, ARE the B
-// operand of O^T += V^T P^T (cdna guide §3 "an accumulator tile as the next MFMA's operand": element
-// jj of lane half h in k-step s is key 16s + 8(jj>>2) + 4h + (jj&3)).  The matching A operand needs,
-// per lane (= one output feature d), 4+4 consecutive keys of V^T; V is therefore transposed per head
-// once (vt_kernel) so those are two 8-byte loads.  No LDS, no barriers: waves are independent.
+// bf16-mode helpers of the transformer path: fp32->bf16 row conversion and the attention core on
+// v_mfma_f32_32x32x16_bf16 (see the comment above attention_bf16_kernel).
 #include "transformer.h"
 
 namespace pt {
@@ -43,132 +36,204 @@ int launch_cvt_f32_bf16(const float* in, int ldi, unsigned short* out, int ldo, 
   return 0;
 }
 
-// V (rows b*Nk + key, 64 features of head h at V + h*64) -> VT[b][h][d][Nkp], keys >= Nk zero filled
-__global__ __launch_bounds__(256) void vt_kernel(const unsigned short* __restrict__ V, int ldv,
-                                                 unsigned short* __restrict__ VT, int Nk, int Nkp, int H) {
-  __shared__ unsigned short tile[32][72];
-  const int k0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-  {
-    const int key = tid >> 3, d8 = (tid & 7) * 8;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (k0 + key < Nk) v = *reinterpret_cast<const u32x4*>(V + (size_t)(b * Nk + k0 + key) * ldv + h * 64 + d8);
-    *reinterpret_cast<u32x4*>(&tile[key][d8]) = v;
-  }
-  __syncthreads();
-  {
-    const int d = tid >> 2, k8 = (tid & 3) * 8;
-    unsigned short o[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = tile[k8 + i][d];
-    u32x4 v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (unsigned)o[2 * i] | ((unsigned)o[2 * i + 1] << 16);
-    *reinterpret_cast<u32x4*>(VT + ((size_t)(b * H + h) * 64 + d) * Nkp + k0 + k8) = v;
-  }
-}
-int launch_vt(const unsigned short* V, int ldv, unsigned short* VT, int B, int Nk, int H, hipStream_t s) {
-  PT_CHECK(B > 0 && Nk > 0 && ldv % 8 == 0 && ((uintptr_t)V & 15) == 0, "vt: bad geometry");
-  const int Nkp = round_up(Nk, 32);
-  PT_LAUNCH(vt_kernel, dim3(Nkp / 32, H, B), dim3(256), 0, s, V, ldv, VT, Nk, Nkp, H);
-  return 0;
-}
-
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attention_bf16_kernel(const unsigned short* __restrict__ Q, int ldq,
+// Attention core softmax(Q K^T / 8) V on v_mfma_f32_32x32x16_bf16, one workgroup per (clip, head).
+//   * K and V of the head (Nk x 64 each) are staged ONCE into LDS by LDS-DMA (global_load_lds_dwordx4) and shared
+//     by the workgroup's waves; each wave owns 32-query tiles.
+//   * S^T = K Q^T ("swapped"): one query per lane column, so softmax runs in registers and the probabilities,
+//     packed pairwise to bf16, ARE the B operand of O^T += V^T P^T (cdna guide §3, accumulator tile as operand:
+//     element jj of lane half h in k-step s is key 16s + 8(jj>>2) + 4h + (jj&3)).
+//   * the matching A operand (V^T: a lane = one feature d, 4+4 consecutive keys) comes from the row-major V
+//     image through ds_read_b64_tr_b16, the hardware transposing read: no V^T copy in HBM any more.
+//   * LDS images are lane-linear per DMA instruction (8 rows x 128 B); bank swizzles live in the per-lane source
+//     address: K chunk ^= (row>>1)&7 (conflict-free ds_read_b128), V chunk ^= ((row>>1)&1)<<2 (conflict-free
+//     transposing reads).
+//   * CT key tiles (32 keys each) are held in registers per softmax step; longer key ranges continue with the
+//     usual running max / sum rescale.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+
+template <int CT>
+__global__ __launch_bounds__(320, 4) void attention_bf16_kernel(const unsigned short* __restrict__ Q, int ldq,
                                                              const unsigned short* __restrict__ K, int ldk,
-                                                             const unsigned short* __restrict__ VT,
+                                                             const unsigned short* __restrict__ V, int ldv,
                                                              unsigned short* __restrict__ O, int ldo, int Nq, int Nk,
-                                                             int Nkp, int H, int qtiles, int total_waves,
-                                                             float scale) {
-  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wid >= total_waves) return;
-  const int lane = threadIdx.x & 63, j = lane & 31, h2 = lane >> 5;
-  const int qt = wid % qtiles, bh = wid / qtiles, head = bh % H, b = bh / H;
-  const int qrow = qt * 32 + j;
-  const bool qvalid = qrow < Nq;
-  const unsigned short* qp = Q + (size_t)(b * Nq + (qvalid ? qrow : Nq - 1)) * ldq + head * 64 + 8 * h2;
-  bf16x8 qf[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
-
-  f32x16 o0, o1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f;
-  const unsigned short* kbase = K + (size_t)b * Nk * ldk + head * 64 + 8 * h2;
-  const unsigned short* vt0 = VT + ((size_t)(b * H + head) * 64 + j) * Nkp + 4 * h2;   // d = j
-  const unsigned short* vt1 = vt0 + (size_t)32 * Nkp;                                  // d = 32 + j
-
-  for (int k0 = 0; k0 < Nk; k0 += 32) {
-    const int krow = k0 + j < Nk ? k0 + j : Nk - 1;
-    const unsigned short* kp = kbase + (size_t)krow * ldk;
-    f32x16 st;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + 16 * s);
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st, 0, 0, 0);
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-      st[r] = key < Nk ? st[r] * scale : -INFINITY;
-      mx = fmaxf(mx, st[r]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
-    float psum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      st[r] = __expf(st[r] - m_new);
-      psum += st[r];
-    }
-    psum += __shfl_xor(psum, 32);
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 pb;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pb[e] = (__bf16)st[8 * s2 + e];
-      // keys k0 + 16 s2 + 4 h2 + {0..3} and + 8 + {0..3}: two 8-byte pieces of this lane's V^T row
-      const u32x2 a0 = *reinterpret_cast<const u32x2*>(vt0 + k0 + 16 * s2);
-      const u32x2 a1 = *reinterpret_cast<const u32x2*>(vt0 + k0 + 16 * s2 + 8);
-      const u32x2 c0 = *reinterpret_cast<const u32x2*>(vt1 + k0 + 16 * s2);
-      const u32x2 c1 = *reinterpret_cast<const u32x2*>(vt1 + k0 + 16 * s2 + 8);
-      const u32x4 va = {a0[0], a0[1], a1[0], a1[1]}, vc = {c0[0], c0[1], c1[0], c1[1]};
-      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), pb, o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vc), pb, o1, 0, 0, 0);
+                                                             int Nkp, int H, int qtiles, float scale) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char att_smem[];
+  unsigned char* Ks = att_smem;
+  unsigned char* Vs = att_smem + (size_t)Nkp * 128;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = blockDim.x >> 6;
+  const int head = blockIdx.x % H, b = blockIdx.x / H;
+  {
+    const unsigned short* kb = K + (size_t)b * Nk * ldk + head * 64;
+    const unsigned short* vb = V + (size_t)b * Nk * ldv + head * 64;
+    for (int R0 = wave * 8; R0 < Nkp; R0 += nw * 8) {
+      const int row = R0 + (lane >> 3);
+      const int srow = row < Nk ? row : Nk - 1;
+      const int gk = (lane & 7) ^ ((row >> 1) & 7);
+      const int gv = (lane & 7) ^ (((row >> 1) & 1) << 2);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(kb + (size_t)srow * ldk + gk * 8), (lds_ptr_t)(Ks + R0 * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(vb + (size_t)srow * ldv + gv * 8), (lds_ptr_t)(Vs + R0 * 128), 16, 0, 0);
     }
   }
-  if (!qvalid) return;
-  const float inv = 1.f / l_run;
-  unsigned short* op = O + (size_t)(b * Nq + qrow) * ldo + head * 64 + 4 * h2;
+  const int j = lane & 31, h2 = lane >> 5;
+  int koff[4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    bf16x4 a, c;
+  for (int s = 0; s < 4; ++s) koff[s] = j * 128 + (((2 * s + h2) ^ ((j >> 1) & 7)) << 4);
+  // transposing read: lane 4q+p of a 16-lane group addresses key row q, features 4p..4p+3 of the group's 16
+  const int tq = (lane >> 2) & 3, tp = lane & 3, tg = (lane >> 4) & 1;
+  const int voff0 = (4 * h2 + tq) * 128 + (((tg * 2 + (tp >> 1)) ^ ((tq >> 1) << 2)) << 4) + (tp & 1) * 8;
+  const int voff1 = voff0 ^ 64;
+  // wave-private 32-query tile image: first the Q rows (DMA, 128-byte rows, K's swizzle), later the output tile
+  // (144-byte rows) on its way to row-contiguous stores
+  constexpr int QO = 32 * 144;
+  unsigned char* Qs = att_smem + (size_t)Nkp * 256 + wave * QO;
+  auto stage_q = [&](int qt) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { a[e] = (__bf16)(o0[4 * g + e] * inv); c[e] = (__bf16)(o1[4 * g + e] * inv); }
-    *reinterpret_cast<bf16x4*>(op + 8 * g) = a;
-    *reinterpret_cast<bf16x4*>(op + 32 + 8 * g) = c;
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 8 + (lane >> 3);
+      int qrow = qt * 32 + row;
+      qrow = qrow < Nq ? qrow : Nq - 1;
+      const int g = (lane & 7) ^ ((row >> 1) & 7);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(Q + (size_t)(b * Nq + qrow) * ldq + head * 64 + g * 8),
+                                       (lds_ptr_t)(Qs + i * 1024), 16, 0, 0);
+    }
+  };
+  stage_q(wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int qt = wave; qt < qtiles; qt += nw) {
+    if (qt != wave) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the previous tile's output reads have left the image
+      stage_q(qt);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(Qs + koff[s]);
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int c0 = 0; c0 < Nkp; c0 += 32 * CT) {
+      f32x16 st[CT];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        if (c0 + 32 * t < Nkp) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (c0 + 32 * t) * 128 + koff[s]);
+            st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[t], 0, 0, 0);
+          }
+          // logits in log2 units (scale * log2 e folded into one multiply); only a partial last tile needs the key mask
+          if (c0 + 32 * t + 32 <= Nk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              st[t][r] *= scale;
+              mx = fmaxf(mx, st[t][r]);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = c0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h2;
+              st[t][r] = key < Nk ? st[t][r] * scale : -INFINITY;
+              mx = fmaxf(mx, st[t][r]);
+            }
+          }
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f(m_run - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        if (c0 + 32 * t < Nkp) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            st[t][r] = __builtin_amdgcn_exp2f(st[t][r] - m_new);
+            psum += st[t][r];
+          }
+        }
+      }
+      psum += __shfl_xor(psum, 32);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+      if (c0 > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      }
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        if (c0 + 32 * t < Nkp) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 pb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pb[e] = (__bf16)st[t][8 * s2 + e];
+            const unsigned char* vrow = Vs + (c0 + 32 * t + 16 * s2) * 128;
+            const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vrow + voff0));
+            const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vrow + 8 * 128 + voff0));
+            const s16x4 c0v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vrow + voff1));
+            const s16x4 c1v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vrow + 8 * 128 + voff1));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 va = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            const s16x8 vc = {c0v[0], c0v[1], c0v[2], c0v[3], c1v[0], c1v[1], c1v[2], c1v[3]};
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), pb, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vc), pb, o1, 0, 0, 0);
+          }
+        }
+      }
+    }
+    // O^T (lane = query, registers = features) -> [query][64 features] image -> 128-byte row stores
+    const float inv = 1.f / l_run;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 a, c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[e] = (__bf16)(o0[4 * g + e] * inv); c[e] = (__bf16)(o1[4 * g + e] * inv); }
+      *reinterpret_cast<bf16x4*>(Qs + j * 144 + (8 * g + 4 * h2) * 2) = a;
+      *reinterpret_cast<bf16x4*>(Qs + j * 144 + (32 + 8 * g + 4 * h2) * 2) = c;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 8 + (lane >> 3);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(Qs + row * 144 + (lane & 7) * 16);
+      const int qrow = qt * 32 + row;
+      if (qrow < Nq) *reinterpret_cast<u32x4*>(O + (size_t)(b * Nq + qrow) * ldo + head * 64 + (lane & 7) * 8) = v;
+    }
   }
 }
 
-int launch_attention_bf16(const unsigned short* Q, int ldq, const unsigned short* K, int ldk,
-                          const unsigned short* VT, unsigned short* O, int ldo, int B, int Nq, int Nk, int H,
-                          hipStream_t s) {
+int launch_attention_bf16(const unsigned short* Q, int ldq, const unsigned short* K, int ldk, const unsigned short* V,
+                          int ldv, unsigned short* O, int ldo, int B, int Nq, int Nk, int H, hipStream_t s) {
   PT_CHECK(B > 0 && Nq > 0 && Nk > 0 && H > 0, "attention_bf16: empty problem");
-  PT_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, "attention_bf16: leading dims must be multiples of 8");
-  PT_CHECK((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)VT) & 15) == 0 && ((uintptr_t)O & 7) == 0,
+  PT_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "attention_bf16: leading dims must be multiples of 8");
+  PT_CHECK((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) == 0,
            "attention_bf16: operands must be 16-byte aligned");
-  const int qtiles = (Nq + 31) / 32, total = B * H * qtiles;
-  PT_LAUNCH(attention_bf16_kernel, dim3((total + 3) / 4), dim3(256), 0, s, Q, ldq, K, ldk, VT, O, ldo, Nq, Nk,
-            round_up(Nk, 32), H, qtiles, total, 0.125f);
+  const int Nkp = round_up(Nk, 32);
+  const int qtiles = (Nq + 31) / 32;
+  const int nw = qtiles < 5 ? qtiles : 5;
+  const size_t smem = (size_t)Nkp * 256 + (size_t)nw * 32 * 144;
+  PT_CHECK(smem <= 160 * 1024, "attention_bf16: %d keys exceed the LDS-resident limit (544)", Nk);
+  constexpr int CT = 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bf16_kernel<CT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  PT_LAUNCH(attention_bf16_kernel<CT>, dim3(B * H), dim3(64 * nw), smem, s, Q, ldq, K, ldk, V, ldv, O, ldo, Nq, Nk, Nkp,
+            H, qtiles, 0.125f * 1.4426950408889634f);
   return 0;
 }
 

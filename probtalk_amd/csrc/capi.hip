@@ -55,8 +55,7 @@ int pt_model_set_precision(pt_model* h, int precision) {
   PT_CHECK(h, "pt_model_set_precision: null model");
   PT_CHECK(!h->m.finalized, "pt_model_set_precision: model already finalized");
   PT_CHECK(precision == 0 || precision == 1, "pt_model_set_precision: %d unsupported (0 = fp32, 1 = bf16)", precision);
-  PT_CHECK(precision == 0 || h->m.kind == "predictor" || h->m.kind == "refiner",
-           "pt_model_set_precision: bf16 mode exists for the predictor and refiner transformers only");
+  PT_CHECK(precision == 0 || h->m.kind != "vqvae_legacy", "pt_model_set_precision: the legacy VQ-VAE has no bf16 mode");
   h->m.precision = precision;
   return 0;
 }
@@ -199,7 +198,7 @@ int pt_prof_read(double* ms8, double* flops8, int* launches8) {
 int pt_gemm_bf16(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, int Npad, float* C,
                  int ldc, void* Cb, int ldcb, int relu, void* stream) {
   PT_CHECK(A && W && (C || Cb), "pt_gemm_bf16: null argument");
-  if (N >= 256 && N % 4 == 0) {   // same dispatch as the transformer sequences (transformer.hip lin_b)
+  if (N >= 256 && N % 8 == 0) {   // same dispatch as the transformer sequences (transformer.hip lin_b)
     GemmBigArgs b;
     memset(&b, 0, sizeof(b));
     b.A = (const unsigned short*)A; b.lda = lda; b.W = (const unsigned short*)W; b.bias = bias;

@@ -120,6 +120,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgsB p, const
 
   const bool plain_rows = (p.out_stride == 1 && p.out_off == 0 && p.Lgrid == p.Lout);
   const int lcol = lane & 31, lrow = 4 * (lane >> 5);
+  const bool gated = (p.act == ACT_GATED);
+  const int n_out = gated ? p.N / 2 : p.N;
+  auto put = [&](int orow, int col, float v) {
+    if (p.C) p.C[(size_t)orow * p.ldc + col] = v;
+    if (p.Cb) reinterpret_cast<__bf16*>(p.Cb)[(size_t)orow * p.ldcb + col] = (__bf16)v;
+  };
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -131,21 +137,37 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgsB p, const
         const int b = m / p.Lgrid;
         orow = b * p.Lout + (m - b * p.Lgrid) * p.out_stride + p.out_off;
       }
+      if (gated) {
+        // weights are interleaved in 32-channel blocks [a | b] (runtime.hip pack_conv): tanh(a) * sigmoid(b)
+        if constexpr (NI % 2 == 0) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int col = n0 + wn * 32 * NI + ni * 32 + lcol;
-        float v = 0.f;
-        const bool real = col < p.N;
-        if (real) {
-          v = acc[mi][ni][r];
-          if (p.bias) v += p.bias[col];
-          if (p.pe) v = (float)((double)v + p.pe[(size_t)(orow % p.pe_period) * p.N + col]);
-          if (p.Res) v += p.Res[(size_t)orow * p.ldr + col];
-          if (p.act == ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+          for (int pr = 0; pr < NI / 2; ++pr) {
+            const int nperm = n0 + wn * 32 * NI + pr * 64 + lcol;
+            const int col = (n0 + wn * 32 * NI + pr * 64) / 2 + lcol;
+            if (col < n_out) {
+              float va = acc[mi][2 * pr][r], vb = acc[mi][2 * pr + 1][r];
+              if (p.bias) { va += p.bias[nperm]; vb += p.bias[nperm + 32]; }
+              put(orow, col, tanhf(va) * (1.f / (1.f + expf(-vb))));
+            } else if (col < p.zero_to) {
+              put(orow, col, 0.f);
+            }
+          }
         }
-        if (real || col < p.zero_to) {
-          if (p.C) p.C[(size_t)orow * p.ldc + col] = v;
-          if (p.Cb) reinterpret_cast<__bf16*>(p.Cb)[(size_t)orow * p.ldcb + col] = (__bf16)v;
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int col = n0 + wn * 32 * NI + ni * 32 + lcol;
+          if (col < n_out) {
+            float v = acc[mi][ni][r];
+            if (p.bias) v += p.bias[col];
+            if (p.pe) v = (float)((double)v + p.pe[(size_t)(orow % p.pe_period) * p.N + col]);
+            if (p.Res) v += p.Res[(size_t)orow * p.ldr + col];
+            if (p.ResB) v += (float)reinterpret_cast<const __bf16*>(p.ResB)[(size_t)orow * p.ldr + col];
+            if (p.act == ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+            put(orow, col, v);
+          } else if (col < p.zero_to) {
+            put(orow, col, 0.f);
+          }
         }
       }
     }
@@ -186,10 +208,17 @@ int launch_gemm_bf16(const GemmArgsB& a, hipStream_t s) {
   PT_CHECK(a.Lgrid > 0 && a.M % a.Lgrid == 0, "gemm_bf16: M=%d is not a multiple of Lgrid=%d", a.M, a.Lgrid);
   PT_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm_bf16: A and W must be 16-byte aligned");
   PT_CHECK(a.C || a.Cb, "gemm_bf16: no output");
-  PT_CHECK((!a.C || a.ldc >= a.N) && (!a.Cb || a.ldcb >= a.N), "gemm_bf16: output leading dim too small for N=%d", a.N);
+  const int n_out = a.act == ACT_GATED ? a.N / 2 : a.N;
+  PT_CHECK((!a.C || (a.ldc >= n_out && a.zero_to <= a.ldc)) && (!a.Cb || (a.ldcb >= n_out && a.zero_to <= a.ldcb)),
+           "gemm_bf16: output leading dim too small for N=%d / zero_to=%d", n_out, a.zero_to);
+  PT_CHECK(!(a.Res && a.ResB), "gemm_bf16: pass the residual as fp32 or bf16, not both");
+  if (a.act == ACT_GATED) {
+    PT_CHECK(a.N % 64 == 0, "gemm_bf16: gated N=%d must be a multiple of 64", a.N);
+    PT_CHECK(!a.pe && !a.Res && !a.ResB, "gemm_bf16: gated epilogue takes no pe/residual");
+  }
   auto tiles = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   if (tiles(128, 128) >= 512) return launch_cfg_b<2, 2>(a, s);
-  if (tiles(64, 128) >= 384) return launch_cfg_b<1, 2>(a, s);
+  if (tiles(64, 128) >= 384 || a.act == ACT_GATED) return launch_cfg_b<1, 2>(a, s);
   return launch_cfg_b<1, 1>(a, s);
 }
 

@@ -23,6 +23,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
@@ -108,14 +109,64 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmBigArgs p, cons
     }
   }
 
-  // ---- epilogue.  acc[mi][ni][4g+e]: row m = .. + mi*32 + r, column n = .. + ni*32 + 8g + 4h + e
-  const int mrow0 = m0 + wm * TM + r, ncol0 = n0 + wn * TN + 4 * h;
+  // ---- epilogue.  acc[mi][ni][4g+e]: row m = .. + mi*32 + r, column n = .. + ni*32 + 8g + 4h + e.
+  // Outputs leave through a wave-private LDS slab (32 rows x TN columns) that turns the accumulator layout
+  // (a lane owns 4 consecutive columns of ONE row: 32 rows per store instruction) into row-contiguous 16-byte
+  // stores (a store instruction covers whole 128..512-byte row segments).
+  constexpr int SLAB = (TN * 4 + 16) * 32;                       // fp32 slab, the larger of the two
+  static_assert(8 * SLAB + 4096 <= 2 * STAGE, "epilogue slabs do not fit the stage memory");
+  unsigned char* slab = smem + wave * SLAB;
+  const int mwave = m0 + wm * TM, nwave = n0 + wn * TN;
+  constexpr int PB = TN * 2 + 16, PF = TN * 4 + 16;              // slab row pitches (bf16 / fp32)
+  auto put_bf16 = [&](int ni, int g, const f32x4& v) {
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+    *reinterpret_cast<bf16x4*>(slab + r * PB + (ni * 32 + 8 * g + 4 * h) * 2) = o;
+  };
+  auto put_f32 = [&](int ni, int g, const f32x4& v) {
+    *reinterpret_cast<f32x4*>(slab + r * PF + (ni * 32 + 8 * g + 4 * h) * 4) = v;
+  };
+  // slab rows -> global, 16 bytes per lane along the row
+  auto flush_bf16 = [&](int mi, unsigned short* out, int ld, int ncols) {
+    constexpr int LPR = TN / 8, RPI = 64 / LPR;
+    const int row = lane / LPR, n = nwave + (lane % LPR) * 8;
+#pragma unroll
+    for (int j = 0; j < 32 / RPI; ++j) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(slab + (j * RPI + row) * PB + (lane % LPR) * 16);
+      const int m = mwave + mi * 32 + j * RPI + row;
+      if (m < p.M && n < ncols) *reinterpret_cast<u32x4*>(out + (size_t)m * ld + n) = v;
+    }
+  };
+  auto flush_f32 = [&](int mi, float* outf, int ldf, unsigned short* outb, int ldb, int ncols) {
+    constexpr int LPR = TN / 4, RPI = 64 / LPR;
+    const int row = lane / LPR, n = nwave + (lane % LPR) * 4;
+#pragma unroll
+    for (int j = 0; j < 32 / RPI; ++j) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(slab + (j * RPI + row) * PF + (lane % LPR) * 16);
+      const int m = mwave + mi * 32 + j * RPI + row;
+      if (m < p.M && n < ncols) {
+        if (outf) *reinterpret_cast<f32x4*>(outf + (size_t)m * ldf + n) = v;
+        if (outb) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(outb) + (size_t)m * ldb + n) = o;
+        }
+      }
+    }
+  };
+
+  const int mrow0 = mwave + r, ncol0 = nwave + 4 * h;
+  __syncthreads();                                  // every wave is done with the stage buffers
   if constexpr (EPI == EPI_STD) {
+    const int ncols = p.N > p.zero_to ? p.N : p.zero_to;   // columns [N, zero_to) are written as zeros
+    const bool via_f32 = p.C != nullptr;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int m = mrow0 + mi * 32;
-      if (m >= p.M) continue;
-      const double* pe_row = p.pe ? p.pe + (size_t)(m % p.pe_period) * p.N : nullptr;
+      const bool live = m < p.M;
+      const double* pe_row = (p.pe && live) ? p.pe + (size_t)(m % p.pe_period) * p.N : nullptr;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
@@ -131,28 +182,20 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmBigArgs p, cons
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = (float)((double)v[e] + pv[e]);
             }
-            if (p.Res) v += *reinterpret_cast<const f32x4*>(p.Res + (size_t)m * p.ldr + n);
+            if (p.Res && live) v += *reinterpret_cast<const f32x4*>(p.Res + (size_t)m * p.ldr + n);
             if (p.relu) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
             }
-          } else if (n >= p.zero_to) {
-            continue;
           }
-          if (p.C) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
-          if (p.Cb) {
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.Cb) + (size_t)m * p.ldcb + n) = o;
-          }
+          if (via_f32) put_f32(ni, g, v); else put_bf16(ni, g, v);
         }
       }
+      if (via_f32) flush_f32(mi, p.C, p.ldc, p.Cb, p.ldcb, ncols); else flush_bf16(mi, p.Cb, p.ldcb, ncols);
     }
   } else {
     // whole rows live in this workgroup (BN == N == 512): LayerNorm over the row, two-pass statistics.
-    float* red = reinterpret_cast<float*>(smem);          // [2][WN][BM], reuses the stage memory
-    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem + 8 * SLAB);          // [2][WN][BM]
     float mean[MI], rstd[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -172,6 +215,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmBigArgs p, cons
             s += acc[mi][ni][4 * g + e];
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
       s += __shfl_xor(s, 32);
       if (h == 0) red[wn * BM + wm * TM + mi * 32 + r] = s;
@@ -202,10 +246,10 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmBigArgs p, cons
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int m = mrow0 + mi * 32;
-      if (m >= p.M) continue;
       const float* st = nullptr;
       if (EPI == EPI_LNMOD) {
-        long long lb = p.label[p.n_label == 1 ? 0 : m / p.rows_per_clip];
+        const int mc = m < p.M ? m : p.M - 1;
+        long long lb = p.label[p.n_label == 1 ? 0 : mc / p.rows_per_clip];
         lb = lb < 0 ? 0 : (lb >= p.n_classes ? p.n_classes - 1 : lb);
         st = p.style + (size_t)lb * 1024;
       }
@@ -227,15 +271,15 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmBigArgs p, cons
               const float t = y[e] * (1.f + sc[e]) + sh[e];
               y[e] = t / (1.f + expf(-t));
             }
+            put_bf16(ni, g, y);
           } else {
-            *reinterpret_cast<f32x4*>(p.X + (size_t)m * 512 + n) = y;
+            put_f32(ni, g, y);
           }
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (__bf16)y[e];
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.Cb) + (size_t)m * p.ldcb + n) = o;
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
+      if (EPI == EPI_ADDLN) flush_f32(mi, p.X, 512, p.Cb, p.ldcb, 512);
+      else flush_bf16(mi, p.Cb, p.ldcb, 512);
     }
   }
 }
@@ -262,22 +306,22 @@ int launch_gemm_big(const GemmBigArgs& a, hipStream_t s) {
   PT_CHECK(a.K % 64 == 0 && a.K > 0, "gemm_big: K=%d must be a positive multiple of 64", a.K);
   PT_CHECK(a.lda >= a.K && a.lda % 8 == 0, "gemm_big: lda=%d must be >= K=%d and a multiple of 8", a.lda, a.K);
   PT_CHECK(a.Npad >= a.N, "gemm_big: Npad=%d < N=%d", a.Npad, a.N);
-  PT_CHECK(a.N % 4 == 0, "gemm_big: N=%d must be a multiple of 4", a.N);
+  PT_CHECK(a.N % 8 == 0, "gemm_big: N=%d must be a multiple of 8", a.N);
   PT_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm_big: A and W must be 16-byte aligned");
   if (a.epi == EPI_STD) {
     PT_CHECK(a.C || a.Cb, "gemm_big: no output");
     PT_CHECK((!a.C || (a.ldc >= a.N && a.ldc % 4 == 0 && ((uintptr_t)a.C & 15) == 0)) &&
-                 (!a.Cb || (a.ldcb >= a.N && a.ldcb % 4 == 0 && ((uintptr_t)a.Cb & 7) == 0)),
-             "gemm_big: output leading dims must be >= N=%d, multiples of 4, and aligned", a.N);
-    PT_CHECK(a.zero_to % 4 == 0 && (a.zero_to == 0 || ((!a.C || a.zero_to <= a.ldc) && (!a.Cb || a.zero_to <= a.ldcb))),
-             "gemm_big: zero_to=%d must be a multiple of 4 within the output rows", a.zero_to);
+                 (!a.Cb || (a.ldcb >= a.N && a.ldcb % 8 == 0 && ((uintptr_t)a.Cb & 15) == 0)),
+             "gemm_big: output leading dims must be >= N=%d, multiples of 4 (fp32) / 8 (bf16), 16-byte aligned", a.N);
+    PT_CHECK(a.zero_to % 8 == 0 && (a.zero_to == 0 || ((!a.C || a.zero_to <= a.ldc) && (!a.Cb || a.zero_to <= a.ldcb))),
+             "gemm_big: zero_to=%d must be a multiple of 8 within the output rows", a.zero_to);
     PT_CHECK(!a.Res || (a.ldr % 4 == 0 && ((uintptr_t)a.Res & 15) == 0), "gemm_big: residual must be 16-byte aligned rows");
     PT_CHECK(!a.pe || (a.pe_period > 0 && ((uintptr_t)a.pe & 31) == 0), "gemm_big: pe table needs a period and 32-byte alignment");
     if (a.N == 512) return launch_big<128, 512, EPI_STD>(a, 7, s);
     return launch_big<256, 256, EPI_STD>(a, 6, s);
   }
   PT_CHECK(a.N == 512, "gemm_big: fused LayerNorm epilogues need N = 512 (got %d)", a.N);
-  PT_CHECK(a.bias && a.gamma && a.beta && a.Cb && a.ldcb >= 512 && a.ldcb % 4 == 0 && ((uintptr_t)a.Cb & 7) == 0,
+  PT_CHECK(a.bias && a.gamma && a.beta && a.Cb && a.ldcb >= 512 && a.ldcb % 8 == 0 && ((uintptr_t)a.Cb & 15) == 0,
            "gemm_big: fused LayerNorm epilogue needs bias, gamma, beta and a bf16 output");
   if (a.epi == EPI_LNMOD) {
     PT_CHECK(a.style && a.label && a.n_label >= 1 && a.rows_per_clip > 0 && a.n_classes > 0,

@@ -11,7 +11,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------
 // (B, C, L) -> rows (b*L + l) of ldo floats at column col_off; columns [C, zero_to-col_off) zeroed.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ncl_to_cl_kernel(const float* __restrict__ in, float* __restrict__ out, int C,
+template <typename OutT>
+__global__ __launch_bounds__(256) void ncl_to_cl_kernel(const float* __restrict__ in, OutT* __restrict__ out, int C,
                                                         int L, int ldo, int col_off, int ccover) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, c0 = blockIdx.y * 32, l0 = blockIdx.x * 32;
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(256) void ncl_to_cl_kernel(const float* __restrict_
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int l = l0 + ty + 8 * i, c = c0 + tx;
-    if (l < L && c < ccover) out[((size_t)b * L + l) * ldo + col_off + c] = tile[tx][ty + 8 * i];
+    if (l < L && c < ccover) out[((size_t)b * L + l) * ldo + col_off + c] = (OutT)tile[tx][ty + 8 * i];
   }
 }
 
@@ -35,7 +36,17 @@ int launch_ncl_to_cl(const float* in, float* out, int B, int C, int L, int ldo, 
   const int ccover = (zero_to > col_off + C ? zero_to - col_off : C);
   PT_CHECK(col_off + ccover <= ldo, "ncl_to_cl: columns %d..%d exceed ld %d", col_off, col_off + ccover, ldo);
   dim3 grid((L + 31) / 32, (ccover + 31) / 32, B);
-  PT_LAUNCH(ncl_to_cl_kernel, grid, dim3(256), 0, s, in, out, C, L, ldo, col_off, ccover);
+  PT_LAUNCH(ncl_to_cl_kernel<float>, grid, dim3(256), 0, s, in, out, C, L, ldo, col_off, ccover);
+  return 0;
+}
+// same with bf16 rows (bf16 mode of the conv stacks)
+int launch_ncl_to_cl_b(const float* in, unsigned short* out, int B, int C, int L, int ldo, int col_off, int zero_to,
+                       hipStream_t s) {
+  PT_CHECK(B > 0 && C > 0 && L > 0, "ncl_to_cl: empty tensor B=%d C=%d L=%d", B, C, L);
+  const int ccover = (zero_to > col_off + C ? zero_to - col_off : C);
+  PT_CHECK(col_off + ccover <= ldo, "ncl_to_cl: columns %d..%d exceed ld %d", col_off, col_off + ccover, ldo);
+  dim3 grid((L + 31) / 32, (ccover + 31) / 32, B);
+  PT_LAUNCH(ncl_to_cl_kernel<__bf16>, grid, dim3(256), 0, s, in, reinterpret_cast<__bf16*>(out), C, L, ldo, col_off, ccover);
   return 0;
 }
 

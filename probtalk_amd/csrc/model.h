@@ -27,7 +27,7 @@ struct DevConv {
   float* b = nullptr;   // [Npad]
   int N = 0, Npad = 0, K = 0, Cin = 0, slabs = 0;
   int merged = 1;       // 2 when a residual conv was folded in (the reference runs two convs)
-  unsigned short* wb = nullptr;  // bf16 copy [Npad][Kb] (1x1 / Linear layers of bf16-mode models)
+  unsigned short* wb = nullptr;  // bf16 copy [slabs][Npad][Kb] (bf16-mode models)
   int Kb = 0;                    // round_up(Cin, 64)
 };
 
@@ -91,6 +91,11 @@ int finalize_model(Model& m);
 int run_conv(const DevConv& c, ConvKind kind, const float* A, int lda, int B, int Lin, float* C, int ldc, int act,
              float slope, const float* Res, int ldr, hipStream_t s, int* Lout = nullptr, int zero_to = -1,
              const double* pe = nullptr, int pe_period = 0);
+
+typedef unsigned short bf16_t;
+int run_conv_b(const DevConv& c, ConvKind kind, const bf16_t* A, int lda, int B, int Lin, float* C, int ldc, bf16_t* Cb,
+               int ldcb, int act, float slope, const bf16_t* ResB, int ldr, hipStream_t s, int* Lout = nullptr,
+               int zero_to = -1);
 
 size_t vqvae_workspace_bytes(const Model& m, int B, int T);
 int vqvae_encode(Model& m, const float* x, int B, int T, float* z, float* quantized, int64_t* indices, void* ws,

@@ -78,7 +78,8 @@ struct GemmArgsB {
   const unsigned short* A; int lda;
   const unsigned short* W;
   const float* bias;
-  const float* Res; int ldr;
+  const float* Res; int ldr;          // fp32 residual (rows of ldr) ...
+  const unsigned short* ResB;         // ... or bf16 residual (same ldr); at most one of the two
   float* C; int ldc;
   unsigned short* Cb; int ldcb;
   const double* pe; int pe_period;
@@ -120,6 +121,8 @@ int launch_gemm_big(const GemmBigArgs& a, hipStream_t s);
 
 // layout
 int launch_ncl_to_cl(const float* in, float* out, int B, int C, int L, int ldo, int col_off, int zero_to, hipStream_t s);
+int launch_ncl_to_cl_b(const float* in, unsigned short* out, int B, int C, int L, int ldo, int col_off, int zero_to,
+                       hipStream_t s);
 int launch_cl_to_ncl(const float* in, int ldi, int col_off, float* out, int B, int C, int L, hipStream_t s);
 
 // product quantizer

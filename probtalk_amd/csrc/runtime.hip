@@ -103,18 +103,19 @@ static int pack_conv(Model& m, DevConv& out, const std::string& w1, const std::s
     hb[pr] = (float)bv;
   }
   if (upload(m, hw, &out.w)) return 1;
-  if (m.precision == 1 && kt == 1 && !gated) {
-    // bf16 copy (round to nearest even) with K padded to the bf16 kernel's 64-element stage
+  if (m.precision == 1) {
+    // bf16 copy (round to nearest even), [slab][Npad][Kb] with K padded to the bf16 kernels' 64-element stage
     out.Kb = round_up(Cin, 64);
-    std::vector<unsigned short> hwb((size_t)out.Npad * out.Kb, 0);
-    for (int n = 0; n < N; ++n)
-      for (int c = 0; c < Cin; ++c) {
-        uint32_t u;
-        const float f = hw[(size_t)n * out.K + c];
-        memcpy(&u, &f, 4);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        hwb[(size_t)n * out.Kb + c] = (unsigned short)(u >> 16);
-      }
+    std::vector<unsigned short> hwb((size_t)kt * out.Npad * out.Kb, 0);
+    for (int k = 0; k < kt; ++k)
+      for (int n = 0; n < out.Npad; ++n)
+        for (int c = 0; c < Cin; ++c) {
+          uint32_t u;
+          const float f = hw[((size_t)k * out.Npad + n) * out.K + c];
+          memcpy(&u, &f, 4);
+          u += 0x7fffu + ((u >> 16) & 1u);
+          hwb[((size_t)k * out.Npad + n) * out.Kb + c] = (unsigned short)(u >> 16);
+        }
     if (upload(m, hwb, &out.wb)) return 1;
   }
   return upload(m, hb, &out.b);
@@ -254,6 +255,68 @@ int run_conv(const DevConv& c, ConvKind kind, const float* A, int lda, int B, in
   return launch_gemm(a, s);
 }
 
+// bf16-operand variant of run_conv (bf16 mode of the conv stacks): A, the residual and the main output are bf16
+// channels-last rows with ld = round_up(C, 64); an fp32 copy of the output is optional (module boundaries).
+int run_conv_b(const DevConv& c, ConvKind kind, const bf16_t* A, int lda, int B, int Lin, float* C, int ldc, bf16_t* Cb,
+               int ldcb, int act, float slope, const bf16_t* ResB, int ldr, hipStream_t s, int* Lout_p, int zero_to) {
+  PT_CHECK(c.wb != nullptr, "conv: bf16 weights were not packed (model precision is fp32)");
+  GemmArgsB a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.W = c.wb; a.bias = c.b; a.ResB = ResB; a.ldr = ldr; a.C = C; a.ldc = ldc; a.Cb = Cb; a.ldcb = ldcb;
+  a.N = c.N; a.K = c.Kb; a.Npad = c.Npad;
+  a.act = act; a.slope = slope;
+  a.Lin = Lin; a.in_stride = 1; a.out_stride = 1; a.out_off = 0;
+  const int n_out = act == ACT_GATED ? c.N / 2 : c.N;
+  a.zero_to = zero_to >= 0 ? zero_to : n_out;
+  PT_CHECK(lda >= c.Kb, "conv(bf16): input leading dim %d < packed K %d", lda, c.Kb);
+  int Lout = Lin;
+  switch (kind) {
+    case CONV_K1:
+      PT_CHECK(c.slabs == 1, "conv: kernel size %d where 1 expected", c.slabs);
+      a.ntaps = 1;
+      break;
+    case CONV_K3:
+    case CONV_K7: {
+      const int kt = kind == CONV_K3 ? 3 : 7;
+      PT_CHECK(c.slabs == kt, "conv: kernel size %d where %d expected", c.slabs, kt);
+      a.ntaps = kt;
+      for (int k = 0; k < kt; ++k) { a.tap_d[k] = k - kt / 2; a.tap_w[k] = k; }
+      break;
+    }
+    case CONV_DOWN:
+      PT_CHECK(c.slabs == 4 && Lin >= 2, "conv(down): kernel size %d / input length %d", c.slabs, Lin);
+      a.ntaps = 4; a.in_stride = 2;
+      for (int k = 0; k < 4; ++k) { a.tap_d[k] = k - 1; a.tap_w[k] = k; }
+      Lout = (Lin - 2) / 2 + 1;
+      break;
+    case CONV_UP:
+      PT_CHECK(c.slabs == 4, "conv: kernel size %d where 4 expected", c.slabs);
+      Lout = 2 * Lin;
+      break;
+  }
+  a.Lout = Lout;
+  if (Lout_p) *Lout_p = Lout;
+  if (kind != CONV_UP) {
+    a.Lgrid = Lout; a.M = B * Lout;
+    a.flops = 2.0 * a.M * c.N * c.Cin * a.ntaps * c.merged;
+    return launch_gemm_bf16(a, s);
+  }
+  a.Lgrid = Lin; a.M = B * Lin; a.out_stride = 2; a.ntaps = 2;
+  a.flops = 2.0 * a.M * c.N * c.Cin * 2 * c.merged;
+  a.out_off = 0; a.tap_d[0] = 0; a.tap_w[0] = 1; a.tap_d[1] = -1; a.tap_w[1] = 3;
+  if (launch_gemm_bf16(a, s)) return 1;
+  a.out_off = 1; a.tap_d[0] = 0; a.tap_w[0] = 2; a.tap_d[1] = 1; a.tap_w[1] = 0;
+  return launch_gemm_bf16(a, s);
+}
+
+static int run_stack_b(const ResStack& st, bf16_t*& h, bf16_t*& t1, bf16_t*& t2, int ld, int B, int L, hipStream_t s) {
+  if (run_conv_b(st.l0, CONV_K3, h, ld, B, L, nullptr, 0, t1, ld, ACT_LEAKY, 0.2f, nullptr, 0, s)) return 1;
+  if (run_conv_b(st.l1, CONV_K3, t1, ld, B, L, nullptr, 0, t2, ld, ACT_LEAKY, 0.2f, nullptr, 0, s)) return 1;
+  if (run_conv_b(st.fin, CONV_K3, t2, ld, B, L, nullptr, 0, t1, ld, ACT_LEAKY, 0.0f, h, ld, s)) return 1;
+  bf16_t* o = h; h = t1; t1 = o;
+  return 0;
+}
+
 // Res_CNR_Stack: h -> relu(BN(conv(cnr(cnr(h)))) + h); result lands in t1, buffers rotate.
 static int run_stack(const ResStack& st, float*& h, float*& t1, float*& t2, int ld, int B, int L, hipStream_t s) {
   if (run_conv(st.l0, CONV_K3, h, ld, B, L, t1, ld, ACT_LEAKY, 0.2f, nullptr, 0, s)) return 1;
@@ -335,8 +398,45 @@ int vqvae_encode(Model& m, const float* x, int B, int T, float* z, float* quanti
   return 0;
 }
 
+int launch_cvt_f32_bf16(const float* in, int ldi, unsigned short* out, int ldo, int rows, int cols, int zero_to,
+                        hipStream_t s);   // bf16ops.hip
+
+// bf16 mode of DecoderSC: every activation between the convs is a bf16 channels-last row; the final projection
+// writes fp32.  The stage buffers are carved from the same arena sizes as the fp32 path (half used).
+static int vqvae_decode_cl_b(Model& m, const float* e_cl, int lde, int B, int Tq, Arena& ar, float** out_cl, int* ld_out,
+                             hipStream_t s) {
+  const VQVAE& v = m.vq;
+  const size_t stage = vq_stage_floats(v, B, Tq, true);
+  bf16_t *h = (bf16_t*)ar.raw(stage * 2), *t1 = (bf16_t*)ar.raw(stage * 2), *t2 = (bf16_t*)ar.raw(stage * 2);
+  bf16_t* eb = (bf16_t*)ar.raw((size_t)B * Tq * lde * 2);
+  const int To = Tq << (v.levels - 1);
+  const int ldo = ld_of(v.in_dim);
+  float* o_cl = ar.f32((size_t)B * To * ldo);
+  PT_CHECK(!ar.overflow, "vqvae_decode: workspace too small (%zu bytes given, %zu needed)", ar.cap, ar.off);
+  for (int i = 0; i < v.levels; ++i) PT_CHECK(v.ch[i] % 64 == 0, "vqvae_decode(bf16): channel plan must be multiples of 64");
+  PT_CHECK(lde % 64 == 0, "vqvae_decode(bf16): latent width %d must be a multiple of 64", lde);
+  if (launch_cvt_f32_bf16(e_cl, lde, eb, lde, B * Tq, lde, lde, s)) return 1;
+  int L = Tq;
+  if (run_conv_b(v.aft_vq, CONV_K1, eb, lde, B, L, nullptr, 0, h, v.ch[v.levels - 1], ACT_NONE, 1.f, nullptr, 0, s)) return 1;
+  for (int i = 0; i < v.levels; ++i) {
+    const int lv = v.levels - 1 - i;
+    if (run_stack_b(v.dec[i], h, t1, t2, v.ch[lv], B, L, s)) return 1;
+    if (i < v.levels - 1) {
+      int Lo;
+      if (run_conv_b(v.up[i], CONV_UP, h, v.ch[lv], B, L, nullptr, 0, t1, v.ch[lv - 1], ACT_LEAKY, 0.2f, nullptr, 0, s, &Lo)) return 1;
+      bf16_t* o = h; h = t1; t1 = o;
+      L = Lo;
+    }
+  }
+  if (run_conv_b(v.dec_project, CONV_K1, h, v.ch[0], B, L, o_cl, ldo, nullptr, 0, ACT_NONE, 1.f, nullptr, 0, s, nullptr, ldo)) return 1;
+  *out_cl = o_cl;
+  *ld_out = ldo;
+  return 0;
+}
+
 int vqvae_decode_cl(Model& m, const float* e_cl, int lde, int B, int Tq, Arena& ar, float** out_cl, int* ld_out,
                     hipStream_t s) {
+  if (m.precision == 1) return vqvae_decode_cl_b(m, e_cl, lde, B, Tq, ar, out_cl, ld_out, s);
   const VQVAE& v = m.vq;
   const size_t stage = vq_stage_floats(v, B, Tq, true);
   float *h = ar.f32(stage), *t1 = ar.f32(stage), *t2 = ar.f32(stage);
@@ -401,9 +501,28 @@ int cond_encoder_forward(Model& m, const float* aud, int B, int T, float* out_nc
   float* h = ar.f32((size_t)B * T * ld);
   float* t = ar.f32((size_t)B * T * ld);
   PT_CHECK(!ar.overflow, "cond_encoder_forward: workspace too small (%zu given, %zu needed)", ws_bytes, ar.off);
+  int L = T;
+  if (m.precision == 1) {
+    // bf16 mode: activations between the convs are bf16 rows living in the (fp32-sized) stage buffers
+    PT_CHECK(ldi % 64 == 0 && ld % 64 == 0, "cond_encoder(bf16): widths %d / %d must be multiples of 64", ldi, ld);
+    bf16_t *ab = (bf16_t*)a_cl, *hb = (bf16_t*)h, *tb = (bf16_t*)t;
+    if (launch_ncl_to_cl_b(aud, ab, B, c.in_dim, T, ldi, 0, ldi, s)) return 1;
+    if (run_conv_b(c.feat, CONV_K1, ab, ldi, B, T, nullptr, 0, hb, ld, ACT_LEAKY, 0.1f, nullptr, 0, s)) return 1;
+    for (int i = 0; i < 2; ++i) {
+      int Lo;
+      if (run_conv_b(c.down[i], CONV_DOWN, hb, ld, B, L, nullptr, 0, tb, ld, ACT_LEAKY, 0.2f, nullptr, 0, s, &Lo)) return 1;
+      bf16_t* o = hb; hb = tb; tb = o;
+      L = Lo;
+    }
+    float* dst = out_cl ? out_cl + col_off : (float*)tb;
+    const int ldd = out_cl ? ld_out_cl : ld;
+    int Lo;
+    if (run_conv_b(c.down[2], CONV_DOWN, hb, ld, B, L, dst, ldd, nullptr, 0, ACT_LEAKY, 0.2f, nullptr, 0, s, &Lo, c.hid)) return 1;
+    if (out_ncl && launch_cl_to_ncl(dst, ldd, 0, out_ncl, B, c.hid, Lo, s)) return 1;
+    return 0;
+  }
   if (launch_ncl_to_cl(aud, a_cl, B, c.in_dim, T, ldi, 0, ldi, s)) return 1;
   if (run_conv(c.feat, CONV_K1, a_cl, ldi, B, T, h, ld, ACT_LEAKY, 0.1f, nullptr, 0, s)) return 1;
-  int L = T;
   for (int i = 0; i < 3; ++i) {
     int Lo;
     const bool last = (i == 2) && out_cl != nullptr;

@@ -21,10 +21,8 @@ int launch_add_ln(float* x, const float* y, const float* gamma, const float* bet
                   hipStream_t s);
 int launch_cvt_f32_bf16(const float* in, int ldi, unsigned short* out, int ldo, int rows, int cols, int zero_to,
                         hipStream_t s);
-int launch_vt(const unsigned short* V, int ldv, unsigned short* VT, int B, int Nk, int H, hipStream_t s);
-int launch_attention_bf16(const unsigned short* Q, int ldq, const unsigned short* K, int ldk,
-                          const unsigned short* VT, unsigned short* O, int ldo, int B, int Nq, int Nk, int H,
-                          hipStream_t s);
+int launch_attention_bf16(const unsigned short* Q, int ldq, const unsigned short* K, int ldk, const unsigned short* V,
+                          int ldv, unsigned short* O, int ldo, int B, int Nq, int Nk, int H, hipStream_t s);
 int launch_mask_onehot(const float* mask, float* cond, int rows, int ld, int c0, int zero_to, hipStream_t s);
 int launch_maskgit_step(const float* logits, const float* noise_q, const float* noise_g, int* ids, int B, int N, int V,
                         int mask_id, int want_mask, float temp, hipStream_t s);
@@ -234,10 +232,9 @@ int finalize_transformer_models(Model& m) {
 // Buffers of one transformer stack.  fp32 mode uses x/qkv/att/t/hb as floats; bf16 mode keeps the residual
 // stream x and the pre-LayerNorm sub-layer outputs t in fp32 and everything that only feeds a GEMM or the
 // attention core (xb, qkv, att, hb) in bf16.
-typedef unsigned short bf16_t;
 struct TBufs {
   float *x = nullptr, *qkv = nullptr, *att = nullptr, *t = nullptr, *hb = nullptr;   // fp32 mode
-  bf16_t *xb = nullptr, *qkvb = nullptr, *attb = nullptr, *hbb = nullptr, *vts = nullptr;  // bf16 mode
+  bf16_t *xb = nullptr, *qkvb = nullptr, *attb = nullptr, *hbb = nullptr;  // bf16 mode
 };
 
 static inline int lin(const DevConv& c, const float* A, int lda, int rows, float* C, int ldc, int act, float slope,
@@ -251,7 +248,7 @@ static int lin_b(const DevConv& c, const bf16_t* A, int lda, int rows, float* C,
                  float slope, hipStream_t s, const double* pe = nullptr, int period = 0) {
   PT_CHECK(c.wb != nullptr, "bf16 weights were not packed for this layer");
   PT_CHECK(lda >= c.Kb, "lin_b: input leading dim %d < packed K %d", lda, c.Kb);
-  if (c.N >= 256 && c.N % 4 == 0 && (act == ACT_NONE || slope == 0.f)) {
+  if (c.N >= 256 && c.N % 8 == 0 && (act == ACT_NONE || slope == 0.f)) {
     GemmBigArgs a;
     memset(&a, 0, sizeof(a));
     a.A = A; a.lda = lda; a.W = c.wb; a.bias = c.b; a.M = rows; a.N = c.N; a.K = c.Kb; a.Npad = c.Npad;
@@ -302,8 +299,8 @@ static int style_then_ln(const StyleW& st, const LNW& ln, TBufs& b, int rows, in
   return launch_add_ln(b.x, b.t, ln.g, ln.b, rows, nullptr, s);
 }
 
-// kv: fp32 mode [Rm, 1024] floats (K | V); bf16 mode the same in bf16 plus vt_cross = V^T per head
-static int decoder_layer(const DecLayer& L, TBufs& b, const void* kv, const bf16_t* vt_cross, int B, int Nq, int Nk,
+// kv: cross-attention K | V rows [Rm, 1024]: floats in fp32 mode, bf16 in bf16 mode
+static int decoder_layer(const DecLayer& L, TBufs& b, const void* kv, int B, int Nq, int Nk,
                          const int64_t* label, int n_label, int n_classes, bool bf, hipStream_t s) {
   const int R = B * Nq;
   if (!bf) {
@@ -322,11 +319,10 @@ static int decoder_layer(const DecLayer& L, TBufs& b, const void* kv, const bf16
   }
   const bf16_t* kvb = (const bf16_t*)kv;
   if (lin_b(L.sa_in, b.xb, DM, R, nullptr, 0, b.qkvb, 3 * DM, ACT_NONE, 1.f, s)) return 1;
-  if (launch_vt(b.qkvb + 2 * DM, 3 * DM, b.vts, B, Nq, NH, s)) return 1;
-  if (launch_attention_bf16(b.qkvb, 3 * DM, b.qkvb + DM, 3 * DM, b.vts, b.attb, DM, B, Nq, Nq, NH, s)) return 1;
+  if (launch_attention_bf16(b.qkvb, 3 * DM, b.qkvb + DM, 3 * DM, b.qkvb + 2 * DM, 3 * DM, b.attb, DM, B, Nq, Nq, NH, s)) return 1;
   if (sublayer_tail_b(L.sa_out, b.attb, DM, b.hbb, L.st[0], L.n1, b.x, b.xb, R, Nq, label, n_label, n_classes, s)) return 1;
   if (lin_b(L.ca_q, b.xb, DM, R, nullptr, 0, b.qkvb, DM, ACT_NONE, 1.f, s)) return 1;
-  if (launch_attention_bf16(b.qkvb, DM, kvb, 2 * DM, vt_cross, b.attb, DM, B, Nq, Nk, NH, s)) return 1;
+  if (launch_attention_bf16(b.qkvb, DM, kvb, 2 * DM, kvb + DM, 2 * DM, b.attb, DM, B, Nq, Nk, NH, s)) return 1;
   if (sublayer_tail_b(L.ca_out, b.attb, DM, b.hbb, L.st[1], L.n2, b.x, b.xb, R, Nq, label, n_label, n_classes, s)) return 1;
   if (lin_b(L.ff1, b.xb, DM, R, nullptr, 0, b.hbb, FF, ACT_LEAKY, 0.f, s)) return 1;
   return sublayer_tail_b(L.ff2, b.hbb, FF, b.attb, L.st[2], L.n3, b.x, b.xb, R, Nq, label, n_label, n_classes, s);
@@ -347,7 +343,6 @@ static TBufs alloc_tbufs(Arena& ar, size_t R, int B, int Nq, bool bf) {
     b.qkvb = (bf16_t*)ar.raw(R * 3 * DM * 2);
     b.attb = (bf16_t*)ar.raw(R * DM * 2);
     b.hbb = (bf16_t*)ar.raw(R * FF * 2);
-    b.vts = (bf16_t*)ar.raw(vt_elems(B, Nq) * 2);
   }
   return b;
 }
@@ -405,6 +400,42 @@ static int predictor_condition_cl(const Predictor& P, const float* masked_motion
   return launch_ncl_to_cl(audio, cond_cl, B, P.audio_dim, L, 768, P.enc[9].dim, P.enc[9].dim + P.audio_dim, s);
 }
 
+// bf16 mode of the motion-context encoder: bf16 rows between the gated convs, fp32 condition rows at the end
+static int predictor_condition_cl_b(const Predictor& P, const float* masked_motion, const float* mask, const float* audio,
+                                    int B, int T, float* cond_cl, Arena& ar, hipStream_t s) {
+  const int ldm = round_up(P.mot_dim + 1, 64);
+  const size_t stage = (size_t)B * T * 128;
+  bf16_t* mm = (bf16_t*)ar.raw((size_t)B * T * ldm * 2);
+  bf16_t *h = (bf16_t*)ar.raw(stage * 2), *g = (bf16_t*)ar.raw(stage * 2), *sk = (bf16_t*)ar.raw(stage * 2),
+         *o = (bf16_t*)ar.raw(stage * 2);
+  PT_CHECK(!ar.overflow, "predictor_condition: workspace too small (%zu given, %zu needed)", ar.cap, ar.off);
+  if (launch_ncl_to_cl_b(masked_motion, mm, B, P.mot_dim, T, ldm, 0, P.mot_dim, s)) return 1;
+  if (launch_ncl_to_cl_b(mask, mm, B, 1, T, ldm, P.mot_dim, ldm, s)) return 1;
+  PT_CHECK(P.motion_emb.N % 64 == 0, "predictor_condition(bf16): motion embedding width must be a multiple of 64");
+  if (run_conv_b(P.motion_emb, CONV_K1, mm, ldm, B, T, nullptr, 0, h, P.motion_emb.N, ACT_NONE, 1.f, nullptr, 0, s)) return 1;
+  int L = T;
+  for (int i = 0; i < 10; ++i) {
+    const GatedW& gw = P.enc[i];
+    const int ldi = gw.in_dim, ldd = gw.dim;
+    PT_CHECK(ldi % 64 == 0 && ldd % 64 == 0, "predictor_condition(bf16): gated conv widths must be multiples of 64");
+    int Lo = L;
+    if (run_conv_b(gw.vert, gw.kind, h, ldi, B, L, nullptr, 0, g, ldd, ACT_GATED, 1.f, nullptr, 0, s, &Lo)) return 1;
+    const bf16_t* res = h;
+    int ldr = ldi;
+    if (gw.strided) {
+      if (run_conv_b(gw.skip, CONV_DOWN, h, ldi, B, L, nullptr, 0, sk, ldd, ACT_NONE, 1.f, nullptr, 0, s)) return 1;
+      res = sk;
+      ldr = ldd;
+    }
+    const bool last = i == 9;
+    if (run_conv_b(gw.res, CONV_K1, g, ldd, B, Lo, last ? cond_cl : nullptr, last ? 768 : 0, last ? nullptr : o, ldd,
+                   ACT_NONE, 1.f, res, ldr, s, nullptr, gw.dim)) return 1;
+    if (!last) { bf16_t* t = h; h = o; o = t; }
+    L = Lo;
+  }
+  return launch_ncl_to_cl(audio, cond_cl, B, P.audio_dim, L, 768, P.enc[9].dim, P.enc[9].dim + P.audio_dim, s);
+}
+
 int predictor_condition(Model& m, const float* masked_motion, const float* mask, const float* audio, int B, int T,
                         float* condition, void* ws, size_t ws_bytes, hipStream_t s) {
   PT_CHECK(m.finalized && m.pred, "predictor_condition: wrong or unfinalized model");
@@ -414,7 +445,8 @@ int predictor_condition(Model& m, const float* masked_motion, const float* mask,
   Arena ar(ws, ws_bytes);
   const int Tq = tq_of(T);
   float* cond_cl = ar.f32((size_t)B * Tq * 768);
-  if (predictor_condition_cl(P, masked_motion, mask, audio, B, T, cond_cl, ar, s)) return 1;
+  if (m.precision == 1 ? predictor_condition_cl_b(P, masked_motion, mask, audio, B, T, cond_cl, ar, s)
+                       : predictor_condition_cl(P, masked_motion, mask, audio, B, T, cond_cl, ar, s)) return 1;
   return launch_cl_to_ncl(cond_cl, 768, 0, condition, B, 768, Tq, s);
 }
 
@@ -422,13 +454,11 @@ struct PredMem {
   float* mem = nullptr;                 // fp32 mode
   bf16_t *condb = nullptr, *memb = nullptr;   // bf16 mode
   std::vector<void*> kv;
-  std::vector<bf16_t*> vt;
 };
 
 static int alloc_predmem(const Predictor& P, Arena& ar, int B, int Tq, bool bf, PredMem& pm) {
   const size_t Rm = (size_t)B * Tq;
   pm.kv.resize(P.n_layers);
-  pm.vt.assign(P.n_layers, nullptr);
   if (!bf) {
     pm.mem = ar.f32(Rm * DM);
     for (int l = 0; l < P.n_layers; ++l) pm.kv[l] = ar.f32(Rm * 2 * DM);
@@ -437,7 +467,6 @@ static int alloc_predmem(const Predictor& P, Arena& ar, int B, int Tq, bool bf, 
     pm.memb = (bf16_t*)ar.raw(Rm * DM * 2);
     for (int l = 0; l < P.n_layers; ++l) {
       pm.kv[l] = ar.raw(Rm * 2 * DM * 2);
-      pm.vt[l] = (bf16_t*)ar.raw(vt_elems(B, Tq) * 2);
     }
   }
   return 0;
@@ -459,7 +488,6 @@ static int predictor_memory(const Predictor& P, const float* cond_cl, int B, int
   for (int l = 0; l < P.n_layers; ++l) {
     bf16_t* kvb = (bf16_t*)pm.kv[l];
     if (lin_b(P.layers[l].ca_kv, pm.memb, DM, Rm, nullptr, 0, kvb, 2 * DM, ACT_NONE, 1.f, s)) return 1;
-    if (launch_vt(kvb + DM, 2 * DM, pm.vt[l], B, Tq, NH, s)) return 1;
   }
   return 0;
 }
@@ -469,7 +497,7 @@ static int predictor_pass(const Predictor& P, const int* ids, const int64_t* lab
   const int N = Tq * P.groups, R = B * N;
   if (launch_embed_pe(ids, P.tok_emb, P.pe, P.ppe, tb.x, tb.xb, R, N, P.groups, P.num_codes + 1, s)) return 1;
   for (int l = 0; l < P.n_layers; ++l)
-    if (decoder_layer(P.layers[l], tb, pm.kv[l], pm.vt[l], B, N, Tq, label, B, P.n_classes, bf, s)) return 1;
+    if (decoder_layer(P.layers[l], tb, pm.kv[l], B, N, Tq, label, B, P.n_classes, bf, s)) return 1;
   if (!bf) {
     if (lin(P.out0, tb.x, DM, R, tb.t, DM, ACT_LEAKY, 0.f, s)) return 1;
     return lin(P.out2, tb.t, DM, R, logits, P.num_codes, ACT_NONE, 1.f, s);
@@ -554,7 +582,7 @@ int refiner_forward(Model& m, const float* x, const float* condition, const floa
   float* o_cl = ar.f32((size_t)rows * ldx);
   TBufs tb = alloc_tbufs(ar, rows, B, T, bf);
   float *mem = nullptr, *kv = nullptr;
-  bf16_t *xb_cl = nullptr, *cb_cl = nullptr, *memb = nullptr, *kvb = nullptr, *vtc = nullptr, *h1b = nullptr;
+  bf16_t *xb_cl = nullptr, *cb_cl = nullptr, *memb = nullptr, *kvb = nullptr, *h1b = nullptr;
   if (!bf) {
     mem = ar.f32((size_t)rows * DM);
     kv = ar.f32((size_t)rows * 2 * DM);
@@ -563,7 +591,6 @@ int refiner_forward(Model& m, const float* x, const float* condition, const floa
     cb_cl = (bf16_t*)ar.raw((size_t)rows * ldc * 2);
     memb = (bf16_t*)ar.raw((size_t)rows * DM * 2);
     kvb = (bf16_t*)ar.raw((size_t)rows * 2 * DM * 2);
-    vtc = (bf16_t*)ar.raw(vt_elems(B, T) * 2);
     h1b = (bf16_t*)ar.raw((size_t)rows * 1024 * 2);
   }
   PT_CHECK(!ar.overflow, "refiner_forward: workspace too small (%zu given, %zu needed)", ws_bytes, ar.off);
@@ -575,7 +602,7 @@ int refiner_forward(Model& m, const float* x, const float* condition, const floa
     if (lin(R.audio_conv, c_cl, ldc, rows, mem, DM, ACT_NONE, 1.f, s, R.pe + DM, T)) return 1;
     for (int l = 0; l < R.n_layers; ++l) {
       if (lin(R.layers[l].ca_kv, mem, DM, rows, kv, 2 * DM, ACT_NONE, 1.f, s)) return 1;
-      if (decoder_layer(R.layers[l], tb, kv, nullptr, B, T, T, label, n_label, R.n_classes, false, s)) return 1;
+      if (decoder_layer(R.layers[l], tb, kv, B, T, T, label, n_label, R.n_classes, false, s)) return 1;
     }
     if (lin(R.out0, tb.x, DM, rows, tb.hb, 1024, ACT_LEAKY, 0.f, s)) return 1;
     if (lin(R.out2, tb.hb, 1024, rows, o_cl, ldx, ACT_NONE, 1.f, s)) return 1;
@@ -586,8 +613,7 @@ int refiner_forward(Model& m, const float* x, const float* condition, const floa
     if (lin_b(R.audio_conv, cb_cl, ldc, rows, nullptr, 0, memb, DM, ACT_NONE, 1.f, s, R.pe + DM, T)) return 1;
     for (int l = 0; l < R.n_layers; ++l) {
       if (lin_b(R.layers[l].ca_kv, memb, DM, rows, nullptr, 0, kvb, 2 * DM, ACT_NONE, 1.f, s)) return 1;
-      if (launch_vt(kvb + DM, 2 * DM, vtc, B, T, NH, s)) return 1;
-      if (decoder_layer(R.layers[l], tb, kvb, vtc, B, T, T, label, n_label, R.n_classes, true, s)) return 1;
+      if (decoder_layer(R.layers[l], tb, kvb, B, T, T, label, n_label, R.n_classes, true, s)) return 1;
     }
     if (lin_b(R.out0, tb.xb, DM, rows, nullptr, 0, h1b, 1024, ACT_LEAKY, 0.f, s)) return 1;
     if (lin_b(R.out2, h1b, 1024, rows, o_cl, ldx, nullptr, 0, ACT_NONE, 1.f, s)) return 1;

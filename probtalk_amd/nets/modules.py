@@ -124,8 +124,8 @@ class _HandleOwner:
         return h
 
     def set_precision(self, precision):
-        """'fp32' (default, parity path) or 'bf16' (bf16 MFMA operands, fp32 accumulate/residual/LayerNorm;
-        predictor and refiner transformers only)."""
+        """'fp32' (default, parity path) or 'bf16' (bf16 MFMA operands, fp32 accumulation; transformers keep an
+        fp32 residual stream and LayerNorm; the PQ-VAE keeps encode + nearest-code search in fp32)."""
         if precision not in ("fp32", "bf16"):
             raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
         if precision == "bf16" and not self._bf16_ok:
@@ -373,9 +373,10 @@ class _VQBase(_HandleOwner, nn.Module):
 
 
 class VQVAE_SC(_VQBase):
-    """vqvae_1d_sc.py:277-324."""
+    """vqvae_1d_sc.py:277-324.  bf16 mode: the conv DECODER runs on bf16 MFMA; encode + code search stay fp32."""
     _kind = "vqvae_sc"
     _levels = 4
+    _bf16_ok = True
 
     def __init__(self, in_dim, embedding_dim, num_embeddings, num_hiddens, num_residual_layers, num_residual_hiddens,
                  commitment_cost=0.25, decay=0.99, q_type='pro', groups=1, share_code=False):
@@ -486,6 +487,7 @@ class VQVAE(_VQBase):
 # ---------------------------------------------------------------------------
 class ConditionEncoder(_HandleOwner, nn.Module):
     _kind = "cond_encoder"
+    _bf16_ok = True
 
     def __init__(self, in_dim, num_hiddens, num_residual_layers, num_residual_hiddens, dp=0.1):
         super().__init__()

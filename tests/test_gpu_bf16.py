@@ -93,6 +93,43 @@ def test_refiner_bf16():
 
 
 def test_bf16_mode_rejected_where_it_does_not_exist():
-    from probtalk_amd.nets.modules import VQVAE_SC
+    from probtalk_amd.nets.modules import VQVAE
     with pytest.raises(NotImplementedError):
-        VQVAE_SC(376, 512, 128, 1024, 2, 512, q_type="pro", groups=4).set_precision("bf16")
+        VQVAE(270, 64, 128, 1024, 2, 512).set_precision("bf16")
+
+
+def test_vq_decoder_bf16_and_encode_stays_exact():
+    """bf16 mode of the PQ-VAE touches the DECODER only: indices stay those of the fp32 search."""
+    from probtalk_amd.nets.modules import VQVAE_SC
+    g = golden("vq_b2_t88.npz")
+    vq = VQVAE_SC(376, 512, 128, 1024, 2, 512, q_type="pro", groups=4).eval()
+    vq.load_state_dict(ref_state_dict("VQ"))
+    vq.set_precision("bf16")
+    x = make_input("vq.x", (2, 376, 88))
+    z, qo, _ = vq.encode(x.cuda())
+    assert torch.equal(qo.loss.cpu(), g["indices"]), "PQ indices changed in bf16 mode"
+    check_bf16(vq.decode(qo.quantized, None).cpu(), g["recon"], "PQ-VAE decoder vs reference golden")
+    # config-3 geometry: codes (B, 37, 4) -> 296 frames
+    sd = ref_state_dict("VQ")
+    codes = make_input("bf.codes", (3, 37, 4), "int", low=0, high=128)
+    ref = O.vqvae_decode(sd, O.pq_quantize_all(sd, "vq_layer.", codes).permute(0, 2, 1))
+    check_bf16(vq.decode_codes(codes.cuda()).cpu(), ref, "PQ-VAE decode_codes T'=37")
+
+
+def test_condition_encoders_bf16():
+    from probtalk_amd.nets.modules import ConditionEncoder
+    ae = ConditionEncoder(768, 256, 2, 256).eval()
+    ae.load_state_dict(ref_state_dict("AudEnc"))
+    ae.set_precision("bf16")
+    sd_a, sd_p = ref_state_dict("AudEnc"), ref_state_dict("Predictor")
+    B, T = 3, 300
+    aud = make_input("bf.aud", (B, 768, T))
+    audio = ae(aud.cuda())
+    ref_audio = O.condition_encoder(sd_a, aud)
+    check_bf16(audio.cpu(), ref_audio, "AudEnc T=300")
+    pn = _predictor()
+    mm = make_input("bf.mm", (B, 376, T))
+    mask = torch.zeros(B, 1, T)
+    mask[:, :, :30] = 1
+    cond = pn.condition(mm.cuda() * mask.cuda(), mask.cuda(), ref_audio.cuda())
+    check_bf16(cond.cpu(), O.predictor_condition(sd_p, mm * mask, mask, ref_audio), "motion-context encoder T=300")
