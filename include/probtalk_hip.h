@@ -118,11 +118,12 @@ int pt_pq_search_cl(const float* z, int ldz, const float* codebooks, int rows, i
 int pt_gemm_bf16(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, int Npad, float* C,
                  int ldc, void* Cb, int ldcb, int relu, void* stream);
 /* Linear to d_model = 512 with the stylization pre-op fused (DeepSupervisionLayer sub-layer output -> StylizationBlock,
- * PTransformer.py:134-139): out_bf16[M,512] = SiLU(LN(A.W^T + bias; gamma, beta) * (1 + style[c][0:512]) + style[c][512:1024]),
- * c = label[row / rows_per_clip] (label[0] when n_label == 1); style is [n_classes][1024] fp32. */
+ * PTransformer.py:134-139): out_bf16[M,512] = SiLU(LN(A.W^T + bias; gamma, beta) * (1 + scale[c]) + shift[c]),
+ * c = label[row / rows_per_clip] (label[0] when n_label == 1).  The LayerNorm affine comes folded into the per-class
+ * table style_folded [n_classes][1024] = gamma*(1+scale[c]) | beta*(1+scale[c]) + shift[c]. */
 int pt_gemm_bf16_lnmod(const void* A, int lda, const void* W, const float* bias, int M, int K, int Npad,
-                       const float* gamma, const float* beta, const float* style, const int64_t* label, int n_label,
-                       int rows_per_clip, int n_classes, void* out_bf16, void* stream);
+                       const float* style_folded, const int64_t* label, int n_label, int rows_per_clip, int n_classes,
+                       void* out_bf16, void* stream);
 /* Linear to d_model = 512 with the post-LN residual fused (PTransformer.py:329-331):
  * x[M,512] = LN(x + A.W^T + bias; gamma, beta) in place (fp32), x_bf16 = its bf16 copy. */
 int pt_gemm_bf16_addln(const void* A, int lda, const void* W, const float* bias, int M, int K, int Npad,

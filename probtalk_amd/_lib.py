@@ -51,7 +51,7 @@ def _proto(lib):
     lib.pt_prof_enable.argtypes = [i]
     lib.pt_prof_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.pt_gemm_bf16.argtypes = [vp, i, vp, vp, i, i, i, i, vp, i, vp, i, i, vp]
-    lib.pt_gemm_bf16_lnmod.argtypes = [vp, i, vp, vp, i, i, i, vp, vp, vp, vp, i, i, i, vp, vp]
+    lib.pt_gemm_bf16_lnmod.argtypes = [vp, i, vp, vp, i, i, i, vp, vp, i, i, i, vp, vp]
     lib.pt_gemm_bf16_addln.argtypes = [vp, i, vp, vp, i, i, i, vp, vp, vp, vp, vp]
     lib.pt_attention_cl.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, vp]
     for name in EXPORTS:

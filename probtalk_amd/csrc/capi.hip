@@ -216,14 +216,14 @@ int pt_gemm_bf16(const void* A, int lda, const void* W, const float* bias, int M
   return launch_gemm_bf16(a, (hipStream_t)stream);
 }
 int pt_gemm_bf16_lnmod(const void* A, int lda, const void* W, const float* bias, int M, int K, int Npad,
-                       const float* gamma, const float* beta, const float* style, const int64_t* label, int n_label,
-                       int rows_per_clip, int n_classes, void* out_bf16, void* stream) {
+                       const float* style_folded, const int64_t* label, int n_label, int rows_per_clip, int n_classes,
+                       void* out_bf16, void* stream) {
   PT_CHECK(A && W && out_bf16, "pt_gemm_bf16_lnmod: null argument");
   GemmBigArgs b;
   memset(&b, 0, sizeof(b));
   b.A = (const unsigned short*)A; b.lda = lda; b.W = (const unsigned short*)W; b.bias = bias;
   b.M = M; b.N = 512; b.K = K; b.Npad = Npad; b.epi = EPI_LNMOD;
-  b.Cb = (unsigned short*)out_bf16; b.ldcb = 512; b.gamma = gamma; b.beta = beta; b.style = style;
+  b.Cb = (unsigned short*)out_bf16; b.ldcb = 512; b.style = style_folded;
   b.label = label; b.n_label = n_label; b.rows_per_clip = rows_per_clip; b.n_classes = n_classes;
   return launch_gemm_big(b, (hipStream_t)stream);
 }

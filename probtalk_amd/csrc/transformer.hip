@@ -33,7 +33,11 @@ int launch_attention(const float* Q, int ldq, const float* K, int ldk, const flo
 constexpr int DM = 512, NH = 8, FF = 2048;
 
 struct LNW { float* g = nullptr; float* b = nullptr; };
-struct StyleW { float* table = nullptr; LNW ln; DevConv out; };
+struct StyleW {
+  float* table = nullptr;   // [n_classes][1024]: scale | shift = emb_layers_2(SiLU(class_embed[c]))
+  float* fold = nullptr;    // [n_classes][1024]: gamma*(1+scale) | beta*(1+scale)+shift (LayerNorm affine folded in; bf16 mode)
+  LNW ln; DevConv out;
+};
 struct DecLayer {
   DevConv sa_in, sa_out, ca_q, ca_kv, ca_out, ff1, ff2;
   LNW n1, n2, n3;
@@ -125,6 +129,17 @@ static int pack_style(Model& m, const std::string& p, const std::string& class_e
   }
   if (upload_v(m, table, &st.table)) return 1;
   if (upload_ln(m, p + "norm_2", st.ln)) return 1;
+  {
+    const HostTensor *g = findt(m, p + "norm_2.weight"), *b = findt(m, p + "norm_2.bias");
+    std::vector<float> fold((size_t)n_classes * 2 * DM);
+    for (int c = 0; c < n_classes; ++c)
+      for (int n = 0; n < DM; ++n) {
+        const float sc = table[(size_t)c * 2 * DM + n], sh = table[(size_t)c * 2 * DM + DM + n];
+        fold[(size_t)c * 2 * DM + n] = g->f[n] * (1.f + sc);
+        fold[(size_t)c * 2 * DM + DM + n] = b->f[n] * (1.f + sc) + sh;
+      }
+    if (upload_v(m, fold, &st.fold)) return 1;
+  }
   return pack_conv_public(m, st.out, p + "out_layers_2.2", "", "", false, false);
 }
 
@@ -279,7 +294,7 @@ static int sublayer_tail_b(const DevConv& last, const bf16_t* A, int lda, bf16_t
   GemmBigArgs a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.W = last.wb; a.bias = last.b; a.M = rows; a.N = DM; a.K = last.Kb; a.Npad = last.Npad;
-  a.epi = EPI_LNMOD; a.Cb = tmp; a.ldcb = DM; a.gamma = st.ln.g; a.beta = st.ln.b; a.style = st.table;
+  a.epi = EPI_LNMOD; a.Cb = tmp; a.ldcb = DM; a.style = st.fold;
   a.label = label; a.n_label = n_label; a.rows_per_clip = rows_per_clip; a.n_classes = n_classes;
   a.flops = 2.0 * rows * DM * last.Cin;
   if (launch_gemm_big(a, s)) return 1;

@@ -60,16 +60,18 @@ def test_big_gemm_lnmod(M, K):
     y = _ln(v, gamma.double(), beta.double()) * (1 + style[lab_row, :512].double()) + style[lab_row, 512:].double()
     ref = y * torch.sigmoid(y)
     out = torch.zeros(M, 512, device="cuda", dtype=torch.bfloat16)
-    Ad, Wd, bd, gd, btd, sd, ld = (t.cuda() for t in (A, W, bias, gamma, beta, style, label))   # keep them alive
-    _lib.check(L.pt_gemm_bf16_lnmod(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, K, Np, _lib.ptr(gd), _lib.ptr(btd),
-                                    _lib.ptr(sd), _lib.ptr(ld), nclip, rpc, 4, _lib.ptr(out), _lib.stream()))
+    # the entry point takes the LayerNorm affine folded into the per-class table: gamma(1+scale) | beta(1+scale)+shift
+    fold = torch.cat([gamma * (1 + style[:, :512]), beta * (1 + style[:, :512]) + style[:, 512:]], dim=1).contiguous()
+    Ad, Wd, bd, sd, ld = (t.cuda() for t in (A, W, bias, fold, label))   # keep them alive
+    _lib.check(L.pt_gemm_bf16_lnmod(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, K, Np, _lib.ptr(sd), _lib.ptr(ld),
+                                    nclip, rpc, 4, _lib.ptr(out), _lib.stream()))
     torch.cuda.synchronize()
     assert float((out.cpu().double() - ref).abs().max()) / float(ref.abs().max()) < 5e-3
     # a single label applies to every row
     out1 = torch.zeros(M, 512, device="cuda", dtype=torch.bfloat16)
     one = torch.tensor([2]).cuda()
-    _lib.check(L.pt_gemm_bf16_lnmod(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, K, Np, _lib.ptr(gd), _lib.ptr(btd),
-                                    _lib.ptr(sd), _lib.ptr(one), 1, rpc, 4, _lib.ptr(out1), _lib.stream()))
+    _lib.check(L.pt_gemm_bf16_lnmod(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, K, Np, _lib.ptr(sd), _lib.ptr(one),
+                                    1, rpc, 4, _lib.ptr(out1), _lib.stream()))
     torch.cuda.synchronize()
     y1 = _ln(v, gamma.double(), beta.double()) * (1 + style[2, :512].double()) + style[2, 512:].double()
     ref1 = y1 * torch.sigmoid(y1)

@@ -47,8 +47,8 @@ for (M, K) in [(75776, 512), (75776, 2048), (153600, 512)]:
     label = torch.randint(0, 4, (M // 148 + 1,), device="cuda")
     out = torch.empty(M, 512, device="cuda", dtype=torch.bfloat16)
     x = torch.randn(M, 512, device="cuda")
-    fns = {"lnmod": lambda: _lib.check(L.pt_gemm_bf16_lnmod(_lib.ptr(A), K, _lib.ptr(W), _lib.ptr(bias), M, K, 512, _lib.ptr(gamma),
-                                                             _lib.ptr(beta), _lib.ptr(style), _lib.ptr(label), M // 148 + 1, 148, 4,
+    fns = {"lnmod": lambda: _lib.check(L.pt_gemm_bf16_lnmod(_lib.ptr(A), K, _lib.ptr(W), _lib.ptr(bias), M, K, 512,
+                                                             _lib.ptr(style), _lib.ptr(label), M // 148 + 1, 148, 4,
                                                              _lib.ptr(out), _lib.stream())),
            "addln": lambda: _lib.check(L.pt_gemm_bf16_addln(_lib.ptr(A), K, _lib.ptr(W), _lib.ptr(bias), M, K, 512, _lib.ptr(gamma),
                                                              _lib.ptr(beta), _lib.ptr(x), _lib.ptr(out), _lib.stream()))}
