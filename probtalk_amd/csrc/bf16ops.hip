@@ -55,8 +55,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
-template <int CT>
-__global__ __launch_bounds__(320, 4) void attention_bf16_kernel(const unsigned short* __restrict__ Q, int ldq,
+template <int CT, int MAXT, int WPE>
+__global__ __launch_bounds__(MAXT, WPE) void attention_bf16_kernel(const unsigned short* __restrict__ Q, int ldq,
                                                              const unsigned short* __restrict__ K, int ldk,
                                                              const unsigned short* __restrict__ V, int ldv,
                                                              unsigned short* __restrict__ O, int ldo, int Nq, int Nk,
@@ -222,18 +222,26 @@ int launch_attention_bf16(const unsigned short* Q, int ldq, const unsigned short
            "attention_bf16: operands must be 16-byte aligned");
   const int Nkp = round_up(Nk, 32);
   const int qtiles = (Nq + 31) / 32;
-  const int nw = qtiles < 5 ? qtiles : 5;
+  const int nw = qtiles <= 10 ? qtiles : (qtiles + 1) / 2 <= 10 ? (qtiles + 1) / 2 : 10;   // waves = query tiles when they fit
   const size_t smem = (size_t)Nkp * 256 + (size_t)nw * 32 * 144;
   PT_CHECK(smem <= 160 * 1024, "attention_bf16: %d keys exceed the LDS-resident limit (544)", Nk);
   constexpr int CT = 2;
   static bool attr_set = false;
   if (!attr_set) {
-    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bf16_kernel<CT>),
+    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bf16_kernel<CT, 320, 4>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bf16_kernel<CT, 640, 3>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  PT_LAUNCH(attention_bf16_kernel<CT>, dim3(B * H), dim3(64 * nw), smem, s, Q, ldq, K, ldk, V, ldv, O, ldo, Nq, Nk, Nkp,
-            H, qtiles, 0.125f * 1.4426950408889634f);
+  // up to 5 query tiles: 5-wave workgroups, 128 registers (two workgroups per CU at 148 keys); longer sequences:
+  // up to 10 waves sharing one K/V image, 168 registers
+  if (nw <= 5)
+    PT_LAUNCH((attention_bf16_kernel<CT, 320, 4>), dim3(B * H), dim3(64 * nw), smem, s, Q, ldq, K, ldk, V, ldv, O, ldo, Nq,
+              Nk, Nkp, H, qtiles, 0.125f * 1.4426950408889634f);
+  else
+    PT_LAUNCH((attention_bf16_kernel<CT, 640, 3>), dim3(B * H), dim3(64 * nw), smem, s, Q, ldq, K, ldk, V, ldv, O, ldo, Nq,
+              Nk, Nkp, H, qtiles, 0.125f * 1.4426950408889634f);
   return 0;
 }
 
