@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libprobtalk_hip.so")
+LIB_PATH = os.environ.get("PROBTALK_HIP_LIB") or os.path.join(_HERE, "libprobtalk_hip.so")   # env: kernel A/B experiments
 
 _lib = None
 

@@ -195,6 +195,9 @@ int pt_prof_read(double* ms8, double* flops8, int* launches8) {
   PT_CHECK(ms8 && flops8 && launches8, "pt_prof_read: null argument");
   return prof_read(ms8, flops8, launches8);
 }
+static unsigned long long* g_stamps = nullptr;
+/* debug aid: device buffer of 256*64 uint64 that the next pt_gemm_bf16* calls fill with phase timestamps */
+int pt_debug_set_stamps(void* buf) { g_stamps = (unsigned long long*)buf; return 0; }
 int pt_gemm_bf16(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, int Npad, float* C,
                  int ldc, void* Cb, int ldcb, int relu, void* stream) {
   PT_CHECK(A && W && (C || Cb), "pt_gemm_bf16: null argument");
@@ -204,6 +207,7 @@ int pt_gemm_bf16(const void* A, int lda, const void* W, const float* bias, int M
     b.A = (const unsigned short*)A; b.lda = lda; b.W = (const unsigned short*)W; b.bias = bias;
     b.M = M; b.N = N; b.K = K; b.Npad = Npad; b.epi = EPI_STD;
     b.C = C; b.ldc = ldc; b.Cb = (unsigned short*)Cb; b.ldcb = ldcb; b.relu = relu;
+    b.stamps = g_stamps;
     return launch_gemm_big(b, (hipStream_t)stream);
   }
   GemmArgsB a;
@@ -223,7 +227,7 @@ int pt_gemm_bf16_lnmod(const void* A, int lda, const void* W, const float* bias,
   memset(&b, 0, sizeof(b));
   b.A = (const unsigned short*)A; b.lda = lda; b.W = (const unsigned short*)W; b.bias = bias;
   b.M = M; b.N = 512; b.K = K; b.Npad = Npad; b.epi = EPI_LNMOD;
-  b.Cb = (unsigned short*)out_bf16; b.ldcb = 512; b.style = style_folded;
+  b.Cb = (unsigned short*)out_bf16; b.ldcb = 512; b.style = style_folded; b.stamps = g_stamps;
   b.label = label; b.n_label = n_label; b.rows_per_clip = rows_per_clip; b.n_classes = n_classes;
   return launch_gemm_big(b, (hipStream_t)stream);
 }
@@ -234,7 +238,7 @@ int pt_gemm_bf16_addln(const void* A, int lda, const void* W, const float* bias,
   memset(&b, 0, sizeof(b));
   b.A = (const unsigned short*)A; b.lda = lda; b.W = (const unsigned short*)W; b.bias = bias;
   b.M = M; b.N = 512; b.K = K; b.Npad = Npad; b.epi = EPI_ADDLN;
-  b.Cb = (unsigned short*)x_bf16; b.ldcb = 512; b.gamma = gamma; b.beta = beta; b.X = x;
+  b.Cb = (unsigned short*)x_bf16; b.ldcb = 512; b.gamma = gamma; b.beta = beta; b.X = x; b.stamps = g_stamps;
   return launch_gemm_big(b, (hipStream_t)stream);
 }
 int pt_attention_cl(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,

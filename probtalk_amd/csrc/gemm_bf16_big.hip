@@ -15,7 +15,13 @@
 //       EPI_LNMOD  out = SiLU(LN(acc + bias) * (1 + scale[label]) + shift[label])  -> bf16   (PTransformer.py:134-139;
 //                  the LayerNorm affine is folded into per-class tables G = gamma(1+scale), B = beta(1+scale)+shift)
 //       EPI_ADDLN  x   = LN(x + acc + bias)                                       -> fp32 x and bf16 copy (:329-331)
+#include <cstdlib>
+
 #include "pt_common.h"
+
+#ifndef PT_DMA_STEPS
+#define PT_DMA_STEPS 4
+#endif
 
 namespace pt {
 
@@ -32,12 +38,18 @@ void prof_record_begin(hipStream_t s, double flops, int cfg, void** tok);
 void prof_record_end(hipStream_t s, void* tok);
 bool prof_is_on();
 
-template <int BM, int BN, int EPI>
-__global__ __launch_bounds__(512) void gemm_big_kernel(const GemmBigArgs p, const int tiles_n, const int ntiles) {
-  constexpr int WN = 4;
-  constexpr int TM = BM / 2, TN = BN / WN, MI = TM / 32, NI = TN / 32;
-  constexpr int ROWS = BM + BN, NLD = ROWS / 64;
-  constexpr int STAGE = ROWS * 128;
+// BM x BN tile, WM x WN waves (wave tile BM/WM x BN/WN), BK = 64 or 32 bf16 per stage.
+template <int BM, int BN, int WM, int WN, int BK, int EPI>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_big_kernel(const GemmBigArgs p, const int tiles_n, const int ntiles) {
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+  constexpr int RB = BK * 2;                          // bytes per LDS row
+  constexpr int RPD = 1024 / RB;                      // rows per DMA wave-instruction (8 or 16)
+  constexpr int CPR = RB / 16;                        // 16-byte chunks per row (8 or 4)
+  constexpr int KS = BK / 16;                         // MFMA k-steps per stage
+  constexpr int ROWS = BM + BN, NLD = ROWS / (RPD * NW), NLDA = BM / (RPD * NW);
+  constexpr int STAGE = ROWS * RB;
+  static_assert(ROWS % (RPD * NW) == 0 && BM % (RPD * NW) == 0, "tile rows must split evenly over the DMA instructions");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
   // Persistent workgroups: gridDim.x <= #CUs, workgroup b runs tiles order(b), order(b) + G, ...  Inside a round
@@ -51,18 +63,20 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmBigArgs p, cons
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WN, wn = wave % WN;
 
-  // ---- staging sources: wave-instruction i of wave w fills tile rows (8 i + w) * 8 .. + 7
+  // ---- staging sources: wave-instruction i of wave w fills tile rows (NW i + w) * RPD .. + RPD-1.  The LDS image
+  // is lane-linear (row-major, RB bytes per row); the bank swizzle is applied to the SOURCE chunk index:
+  // BK=64: chunk ^= (row>>1)&7, BK=32: chunk ^= (row>>2)&3 (both conflict-free for the ds_read_b128 fragment reads).
   // (32-bit byte offsets from the uniform A / W base: the DMA instructions take base in SGPRs + offset VGPR)
   unsigned soff[NLD];
   auto set_src = [&](int tl) {
     const int tm = tl / tiles_n, tn = tl - tm * tiles_n;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int R = (i * 8 + wave) * 8 + (lane >> 3);
-      const int g = (lane & 7) ^ ((R >> 1) & 7);
-      if (i < BM / 64) {
+      const int R = (i * NW + wave) * RPD + lane / CPR;
+      const int g = (lane % CPR) ^ (BK == 64 ? ((R >> 1) & 7) : ((R >> 2) & 3));
+      if (i < NLDA) {
         int m = tm * BM + R;
         m = m < p.M ? m : p.M - 1;
         soff[i] = ((unsigned)m * (unsigned)p.lda + g * 8) * 2u;
@@ -75,58 +89,75 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmBigArgs p, cons
   };
   // issue wave-instructions [i0, i1) of the stage that fills buffer `buf` with K-tile `kt`
   auto stage = [&](int buf, int kt, int i0, int i1) {
-    const unsigned char* abase = reinterpret_cast<const unsigned char*>(p.A) + (size_t)kt * 128;
-    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.W) + (size_t)kt * 128;
+    const unsigned char* abase = reinterpret_cast<const unsigned char*>(p.A) + (size_t)kt * RB;
+    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.W) + (size_t)kt * RB;
 #pragma unroll
     for (int i = 0; i < NLD; ++i)
       if (i >= i0 && i < i1)
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)((i < BM / 64 ? abase : wbase) + soff[i]),
-                                         (lds_ptr_t)(smem + buf * STAGE + (i * 8 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)((i < NLDA ? abase : wbase) + soff[i]),
+                                         (lds_ptr_t)(smem + buf * STAGE + (i * NW + wave) * 1024), 16, 0, 0);
   };
 
   const int r = lane & 31, h = lane >> 5;
-  int off[4];
+  int off[KS];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) off[s] = r * 128 + (((2 * s + h) ^ ((r >> 1) & 7)) << 4);
+  for (int s = 0; s < KS; ++s)
+    off[s] = r * RB + (((2 * s + h) ^ (BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3))) << 4);
 
   // epilogue slabs: wave-private LDS images (32 rows of bf16, or of one fp32 column half) inside the stage buffer the tile used
   // LAST; the other buffer is already receiving the next tile's first K-tile.
   constexpr int PB = TN * 2 + 16, PF = TN * 2 + 16;              // slab row pitches (bf16 rows / fp32 half rows)
   constexpr int SLAB = PB * 32;
-  static_assert(8 * SLAB + 4096 <= STAGE, "epilogue slabs do not fit one stage buffer");
+  static_assert(NW * SLAB + (EPI == EPI_STD ? 0 : 2 * WN * BM * 4) <= STAGE, "epilogue slabs do not fit one stage buffer");
 
-  const int nt = p.K / 64;
+  const int nt = p.K / BK;
   int gt = 0;                                          // K-tiles done so far (buffer parity runs across tiles)
   if (tile < ntiles) {
     set_src(tile);
     stage(0, 0, 0, NLD);
   }
+  int stamp_i = 0;
+  auto stamp = [&]() {
+    if (p.stamps && tid == 0 && stamp_i < 64 && blockIdx.x < 256) p.stamps[blockIdx.x * 64 + stamp_i++] = __builtin_amdgcn_s_memrealtime();
+  };
   for (; tile < ntiles; tile += G) {
+    stamp();                                            // [0] tile start
     const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // accumulators start at the bias (its loads overlap the wait for the tile's first K-tile, which is idle time)
     f32x16 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * TN + 4 * (lane >> 5) + ni * 32 + 8 * g;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[mi][ni][4 * g + e] = bv[e];
+      }
 
     for (int t = 0; t < nt; ++t, ++gt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                     // K-tile landed for every wave; everyone is done with the other buffer
+      if (t == 0) stamp();                 // [1] first K-tile landed
       const bool more = t + 1 < nt;
-      const unsigned char* Ab = smem + (gt & 1) * STAGE + (wm * TM) * 128;
-      const unsigned char* Bb = smem + (gt & 1) * STAGE + (BM + wn * TN) * 128;
+      const unsigned char* Ab = smem + (gt & 1) * STAGE + (wm * TM) * RB;
+      const unsigned char* Bb = smem + (gt & 1) * STAGE + (BM + wn * TN) * RB;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < KS; ++s) {
         bf16x8 a[MI], b[NI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(Ab + mi * 4096 + off[s]);
+        for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(Ab + mi * 32 * RB + off[s]);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(Bb + ni * 4096 + off[s]);
-        // the next K-tile's DMA is spread over the four k-steps so its issue hides behind this step's MFMAs
-        if (more) stage((gt + 1) & 1, t + 1, s * NLD / 4, (s + 1) * NLD / 4);
+        for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(Bb + ni * 32 * RB + off[s]);
+        // the next K-tile's DMA is spread over the k-steps so its issue hides behind this step's MFMAs
+        if (more) {
+          constexpr int DS = PT_DMA_STEPS < KS ? PT_DMA_STEPS : KS;     // k-steps that carry DMA issue
+          if (s < DS) stage((gt + 1) & 1, t + 1, s * NLD / DS, (s + 1) * NLD / DS);
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -135,6 +166,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmBigArgs p, cons
       }
     }
     __syncthreads();                                   // every wave is done with the stage buffers of this tile
+    stamp();                                           // [2] main loop done
     unsigned char* ebuf = smem + ((gt - 1) & 1) * STAGE;          // free now: slabs and reduction scratch
     unsigned char* slab = ebuf + wave * SLAB;
     const bool has_next = tile + G < ntiles;
@@ -150,15 +182,13 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmBigArgs p, cons
         for (int g = 0; g < 4; ++g) {
           const int n = ncol0 + ni * 32 + 8 * g;
           const bool real = n < p.N;
-          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-          if (real && p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) {
             const int m = mrow0 + mi * 32;
             const bool live = m < p.M;
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e] + bv[e];
+            for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e];
             if (p.pe && real && live) {
               const f64x4 pv = *reinterpret_cast<const f64x4*>(p.pe + (size_t)(m % p.pe_period) * p.N + n);
 #pragma unroll
@@ -175,27 +205,35 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmBigArgs p, cons
       }
     } else {
       // whole rows live in this workgroup (BN == N == 512): LayerNorm over the row, two-pass statistics.
-      float* red = reinterpret_cast<float*>(ebuf + 8 * SLAB);          // [2][WN][BM]
+      float* red = reinterpret_cast<float*>(ebuf + NW * SLAB);         // [2][WN][BM]
       float mean[MI], rstd[MI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int m = mrow0 + mi * 32;
         const bool live = m < p.M;
         float sum = 0.f;
+        if (EPI == EPI_ADDLN) {
+          // the row's 16 residual quads are requested together (memory-level parallelism), one row block at a time
+          f32x4 xv[NI][4];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              xv[ni][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+              if (live) xv[ni][g] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * 512 + ncol0 + ni * 32 + 8 * g);
+            }
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[mi][ni][4 * g + e] += xv[ni][g][e];
+        }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int n = ncol0 + ni * 32 + 8 * g;
-            f32x4 add = *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (EPI == EPI_ADDLN && live) add += *reinterpret_cast<const f32x4*>(p.X + (size_t)m * 512 + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              acc[mi][ni][4 * g + e] += add[e];
-              sum += acc[mi][ni][4 * g + e];
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
+          for (int e = 0; e < 16; ++e) sum += acc[mi][ni][e];
+          asm volatile("" : "+v"(acc[mi][ni]) :: "memory");
         }
         sum += __shfl_xor(sum, 32);
         if (h == 0) red[wn * BM + wm * TM + mi * 32 + r] = sum;
@@ -204,7 +242,10 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmBigArgs p, cons
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int lr = wm * TM + mi * 32 + r;
-        mean[mi] = (red[lr] + red[BM + lr] + red[2 * BM + lr] + red[3 * BM + lr]) * (1.f / 512.f);
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) tot += red[w * BM + lr];
+        mean[mi] = tot * (1.f / 512.f);
         float q = 0.f;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
@@ -221,7 +262,10 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmBigArgs p, cons
       for (int mi = 0; mi < MI; ++mi) {
         const int lr = wm * TM + mi * 32 + r;
         const float* rq = red + WN * BM;
-        rstd[mi] = __builtin_amdgcn_rsqf((rq[lr] + rq[BM + lr] + rq[2 * BM + lr] + rq[3 * BM + lr]) * (1.f / 512.f) + 1e-5f);
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) tot += rq[w * BM + lr];
+        rstd[mi] = __builtin_amdgcn_rsqf(tot * (1.f / 512.f) + 1e-5f);
       }
       // normalise in place.  LNMOD: the per-class tables hold gamma*(1+scale) and beta*(1+scale)+shift, so
       // SiLU(LN(v)*(1+scale)+shift) = SiLU((v-mean)*rstd*G[c] + B[c])
@@ -237,16 +281,27 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmBigArgs p, cons
           gp = p.style + (size_t)lb * 1024;
           bp = gp + 512;
         }
+        // table rows of the next 32-column block are requested before this block's arithmetic (software pipeline)
+        f32x4 ga[2][4], be[2][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          ga[0][g] = *reinterpret_cast<const f32x4*>(gp + ncol0 + 8 * g);
+          be[0][g] = *reinterpret_cast<const f32x4*>(bp + ncol0 + 8 * g);
+        }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
+          if (ni + 1 < NI) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              ga[(ni + 1) & 1][g] = *reinterpret_cast<const f32x4*>(gp + ncol0 + (ni + 1) * 32 + 8 * g);
+              be[(ni + 1) & 1][g] = *reinterpret_cast<const f32x4*>(bp + ncol0 + (ni + 1) * 32 + 8 * g);
+            }
+          }
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const int n = ncol0 + ni * 32 + 8 * g;
-            const f32x4 ga = *reinterpret_cast<const f32x4*>(gp + n);
-            const f32x4 be = *reinterpret_cast<const f32x4*>(bp + n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              float y = (acc[mi][ni][4 * g + e] - mean[mi]) * rstd[mi] * ga[e] + be[e];
+              float y = (acc[mi][ni][4 * g + e] - mean[mi]) * rstd[mi] * ga[ni & 1][g][e] + be[ni & 1][g][e];
               if (EPI == EPI_LNMOD) y = y * __builtin_amdgcn_rcpf(1.f + __expf(-y));
               acc[mi][ni][4 * g + e] = y;
             }
@@ -263,6 +318,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmBigArgs p, cons
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
 
+    stamp();                                           // [3] epilogue arithmetic done
     // ---- the next tile's first K-tile starts flowing into the other buffer while this tile is stored
     if (has_next) {
       set_src(tile + G);
@@ -329,16 +385,18 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmBigArgs p, cons
         }
       }
     }
+    stamp();                                           // [4] stores issued
   }
 }
 
 static int g_num_cus = 0;
-template <int BM, int BN, int EPI>
+// WPC workgroups per CU are resident (LDS / register budget of the configuration); the persistent grid is WPC x #CUs.
+template <int BM, int BN, int WM, int WN, int BK, int EPI, int WPC>
 static int launch_big(const GemmBigArgs& a, int cfg, hipStream_t s) {
-  constexpr size_t smem = 2 * (size_t)(BM + BN) * 128;
+  constexpr size_t smem = 2 * (size_t)(BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<BM, BN, EPI>),
+    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<BM, BN, WM, WN, BK, EPI>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
   }
@@ -349,12 +407,22 @@ static int launch_big(const GemmBigArgs& a, int cfg, hipStream_t s) {
     g_num_cus = n > 0 ? n : 256;
   }
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
-  const int grid = ntiles < g_num_cus ? ntiles : g_num_cus;      // persistent: one workgroup per CU loops over tiles
+  const int slots = WPC * g_num_cus;
+  const int grid = ntiles < slots ? ntiles : slots;      // persistent: resident workgroups loop over the tiles
   void* tok = nullptr;
   if (prof_is_on()) prof_record_begin(s, a.flops > 0 ? a.flops : 2.0 * a.M * a.N * a.K, cfg, &tok);
-  PT_LAUNCH((gemm_big_kernel<BM, BN, EPI>), dim3(grid), dim3(512), smem, s, a, tiles_n, ntiles);
+  PT_LAUNCH((gemm_big_kernel<BM, BN, WM, WN, BK, EPI>), dim3(grid), dim3(64 * WM * WN), smem, s, a, tiles_n, ntiles);
   if (tok) prof_record_end(s, tok);
   return 0;
+}
+
+// row-complete (N = 512) configuration: 0 = 128x512 tiles, 8 waves, BK 64, one workgroup per CU (default);
+// 1 = 64x512 tiles, 4 waves, BK 32, two workgroups per CU: measured 1.8x SLOWER (each 64-row tile still streams the
+// whole 512 x K weight panel through the CU's L2 port, ~13 us per panel either way).  PT_GEMM_ROWCFG=1 selects it.
+static int row_cfg() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PT_GEMM_ROWCFG"); v = e ? atoi(e) : 0; }
+  return v;
 }
 
 int launch_gemm_big(const GemmBigArgs& a, hipStream_t s) {
@@ -374,8 +442,8 @@ int launch_gemm_big(const GemmBigArgs& a, hipStream_t s) {
              "gemm_big: zero_to=%d must be a multiple of 8 within the output rows", a.zero_to);
     PT_CHECK(!a.Res || (a.ldr % 4 == 0 && ((uintptr_t)a.Res & 15) == 0), "gemm_big: residual must be 16-byte aligned rows");
     PT_CHECK(!a.pe || (a.pe_period > 0 && ((uintptr_t)a.pe & 31) == 0), "gemm_big: pe table needs a period and 32-byte alignment");
-    if (a.N == 512) return launch_big<128, 512, EPI_STD>(a, 7, s);
-    return launch_big<256, 256, EPI_STD>(a, 6, s);
+    if (a.N == 512) return row_cfg() == 0 ? launch_big<128, 512, 2, 4, 64, EPI_STD, 1>(a, 7, s) : launch_big<64, 512, 1, 4, 32, EPI_STD, 2>(a, 7, s);
+    return launch_big<256, 256, 2, 4, 64, EPI_STD, 1>(a, 6, s);
   }
   PT_CHECK(a.N == 512, "gemm_big: fused LayerNorm epilogues need N = 512 (got %d)", a.N);
   PT_CHECK(a.bias && a.Cb && a.ldcb >= 512 && a.ldcb % 8 == 0 && ((uintptr_t)a.Cb & 15) == 0,
@@ -385,11 +453,11 @@ int launch_gemm_big(const GemmBigArgs& a, hipStream_t s) {
              "gemm_big: LNMOD epilogue needs the style table and labels");
     PT_CHECK(a.n_label == 1 || (long long)a.n_label * a.rows_per_clip >= a.M, "gemm_big: %d labels x %d rows < M=%d",
              a.n_label, a.rows_per_clip, a.M);
-    return launch_big<128, 512, EPI_LNMOD>(a, 7, s);
+    return row_cfg() == 0 ? launch_big<128, 512, 2, 4, 64, EPI_LNMOD, 1>(a, 7, s) : launch_big<64, 512, 1, 4, 32, EPI_LNMOD, 2>(a, 7, s);
   }
   PT_CHECK(a.epi == EPI_ADDLN && a.X && a.gamma && a.beta && ((uintptr_t)a.X & 15) == 0,
            "gemm_big: ADDLN epilogue needs gamma, beta and the residual stream X");
-  return launch_big<128, 512, EPI_ADDLN>(a, 7, s);
+  return row_cfg() == 0 ? launch_big<128, 512, 2, 4, 64, EPI_ADDLN, 1>(a, 7, s) : launch_big<64, 512, 1, 4, 32, EPI_ADDLN, 2>(a, 7, s);
 }
 
 }  // namespace pt
