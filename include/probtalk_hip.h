@@ -142,6 +142,69 @@ int pt_prof_read(double* ms8, double* flops8, int* launches8);
 int pt_pq_gather_cl(const void* idx, int idx_are_int64, const float* codebooks, int rows, int G, int D, int K,
                     float* out, int ldq, void* stream);
 
+/* ---- training-mode operators (train.hip): predictor train step of predictor.py:168-280 ---------------------------
+ * All tensors are channels-last fp32 rows [B*L, ld] as in the op-level block above.  The forward GEMMs and the
+ * input-gradient GEMMs of the train step are pt_conv1d_cl itself (input gradient = the same tap-GEMM on dY with
+ * transposed weights, see train.hip); what is added here is everything else the backward pass and the optimizer need.
+ * `kind` as in pt_conv1d_cl. */
+/* token embedding + fp64 positional encodings (PTransformer.py:447-474): x[row] = float(double(tok[id]) + (pe[t+1] + ppe[g+1])) */
+int pt_embed_pe(const int32_t* ids, const float* tok, const double* pe, const double* ppe, float* x, int rows, int N, int G,
+                int vocab, void* stream);
+/* weight gradient of a conv/linear (the `.grad` autograd gives nn.Conv1d / nn.Linear weights): dW [taps][N][Cin] (pre-zeroed) +=
+ * sum over rows of dY[row][n] * X[tap-shifted row][c] */
+int pt_train_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int N, int Cin, int kind, int B, int Lin,
+                   void* stream);
+/* out[c] += sum_rows a[row][c] (* b[row][c] if b): bias gradients */
+int pt_train_colsum(const float* a, int lda, const float* b, int ldb, int rows, int cols, float* out, void* stream);
+/* nn.LayerNorm(512) on x (+ res): y, stats[rows][2] = mean, rstd; backward gives dx (w.r.t. x + res), dgamma, dbeta (+=) */
+int pt_train_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y, float* stats, int rows,
+                    void* stream);
+int pt_train_ln_bwd(const float* dy, const float* x, const float* res, const float* stats, const float* gamma, float* dx,
+                    float* dgamma, float* dbeta, int rows, void* stream);
+/* StylizationBlock_V3 'sb' modulation (PTransformer.py:134-139): h = SiLU(y*(1+scale[c]) + shift[c]), table [n_classes][1024] */
+int pt_train_modsilu_fwd(const float* y, const float* table, const int64_t* label, int n_label, int rows_per_clip, int n_classes,
+                         float* h, int rows, void* stream);
+int pt_train_modsilu_bwd(const float* dh, const float* y, const float* table, const int64_t* label, int n_label,
+                         int rows_per_clip, int n_classes, float* dy, float* dtable, int rows, void* stream);
+/* nn.MultiheadAttention core in train mode (dropout p on the attention weights, mask = hash(seed, b, h, i, j)) and its
+ * backward (probabilities recomputed; lse / delta are [B*H*Nq] scratch outputs) */
+int pt_train_attention_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,
+                           int Nq, int Nk, int H, float pdrop, uint64_t seed, void* stream);
+int pt_train_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* dO, int ldo,
+                           float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, float* lse, float* delta, int B,
+                           int Nq, int Nk, int H, float pdrop, uint64_t seed, void* stream);
+/* F.cross_entropy(logits [rows,V], target) mean (predictor.py:261): *loss (pre-zeroed) and dlogits */
+int pt_train_cross_entropy(const float* logits, const int64_t* target, int V, int rows, float* loss, float* dlogits,
+                           void* stream);
+/* nn.BatchNorm1d in train mode + residual + (leaky) ReLU of ConvNormRelu (vqvae_modules.py:193-200): batch statistics over
+ * the rows, running statistics updated in place (may be NULL); slope < 0 = no activation.  acc_ws: 2*cols doubles. */
+int pt_train_bn_fwd(const float* x, int ldx, int rows, int cols, const float* gamma, const float* beta, const float* res, int ldr,
+                    float slope, float* y, int ldy, float* mean_rstd, double* acc_ws, float* run_mean, float* run_var,
+                    float momentum, void* stream);
+/* backward: dz = gradient before the activation (also the residual branch's gradient), dx, sums [2][cols] = dbeta | dgamma */
+int pt_train_bn_bwd(const float* dy, int lddy, const float* y, int ldy, float slope, const float* x, int ldx,
+                    const float* mean_rstd, const float* gamma, float* dz, int lddz, float* dx, int lddx, float* sums, int rows,
+                    int cols, void* stream);
+int pt_train_act_bwd(const float* dy, int lddy, const float* y, int ldy, float slope, float* dz, int lddz, int rows, int cols,
+                     void* stream);
+/* GatedActivation (gated_pixelcnn_1d.py:30-36): out = tanh(a) * sigmoid(b), hv rows = [a | b] */
+int pt_train_gate_fwd(const float* hv, int rows, int C, float* out, void* stream);
+int pt_train_gate_bwd(const float* dout, const float* hv, int rows, int C, float* dhv, void* stream);
+/* nn.Embedding gradient: dE[ids[row]] += dx[row] (512 wide) */
+int pt_train_embed_bwd(const float* dx, const int32_t* ids, int rows, int vocab, float* dE, void* stream);
+/* nn.Dropout: y = x * mask / (1-p), mask = hash(seed, element) (call again on dy with the same seed for the backward) */
+int pt_train_dropout(const float* x, float* y, size_t n, float p, uint64_t seed, void* stream);
+/* torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW (predictor.py:112-118,270-278): *out += sum g^2; coef = min(1,
+ * max_norm / (sqrt(sumsq) + 1e-6)); AdamW update with the gradient scaled by *gscale (device scalar, may be NULL) */
+int pt_train_sumsq(const float* g, size_t n, float* out, void* stream);
+int pt_train_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
+int pt_train_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* gscale, float lr, float beta1,
+                   float beta2, float eps, float wd, int step, void* stream);
+int pt_train_add(const float* a, const float* b, float* out, size_t n, void* stream);
+/* debug aid: device buffer of 256*64 uint64 that the following pt_gemm_bf16* calls fill with per-workgroup phase
+ * timestamps (tools/gemm_stamps.py); NULL switches it off */
+int pt_debug_set_stamps(void* buf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,29 @@ def _proto(lib):
     lib.pt_gemm_bf16.argtypes = [vp, i, vp, vp, i, i, i, i, vp, i, vp, i, i, vp]
     lib.pt_gemm_bf16_lnmod.argtypes = [vp, i, vp, vp, i, i, i, vp, vp, i, i, i, vp, vp]
     lib.pt_gemm_bf16_addln.argtypes = [vp, i, vp, vp, i, i, i, vp, vp, vp, vp, vp]
+    f, u64, sz = C.c_float, C.c_uint64, C.c_size_t
+    lib.pt_embed_pe.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
+    lib.pt_train_wgrad.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, vp]
+    lib.pt_train_colsum.argtypes = [vp, i, vp, i, i, i, vp, vp]
+    lib.pt_train_ln_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, vp]
+    lib.pt_train_ln_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, vp]
+    lib.pt_train_modsilu_fwd.argtypes = [vp, vp, vp, i, i, i, vp, i, vp]
+    lib.pt_train_modsilu_bwd.argtypes = [vp, vp, vp, vp, i, i, i, vp, vp, i, vp]
+    lib.pt_train_attention_fwd.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, f, u64, vp]
+    lib.pt_train_attention_bwd.argtypes = [vp, i, vp, i, vp, i, vp, i, vp, i, vp, i, vp, i, vp, vp, i, i, i, i, f, u64, vp]
+    lib.pt_train_cross_entropy.argtypes = [vp, vp, i, i, vp, vp, vp]
+    lib.pt_train_bn_fwd.argtypes = [vp, i, i, i, vp, vp, vp, i, f, vp, i, vp, vp, vp, vp, f, vp]
+    lib.pt_train_bn_bwd.argtypes = [vp, i, vp, i, f, vp, i, vp, vp, vp, i, vp, i, vp, i, i, vp]
+    lib.pt_train_act_bwd.argtypes = [vp, i, vp, i, f, vp, i, i, i, vp]
+    lib.pt_train_gate_fwd.argtypes = [vp, i, i, vp, vp]
+    lib.pt_train_gate_bwd.argtypes = [vp, vp, i, i, vp, vp]
+    lib.pt_train_embed_bwd.argtypes = [vp, vp, i, i, vp, vp]
+    lib.pt_train_dropout.argtypes = [vp, vp, sz, f, u64, vp]
+    lib.pt_train_sumsq.argtypes = [vp, sz, vp, vp]
+    lib.pt_train_clip_coef.argtypes = [vp, f, vp, vp, vp]
+    lib.pt_train_adamw.argtypes = [vp, vp, vp, vp, sz, vp, f, f, f, f, f, i, vp]
+    lib.pt_train_add.argtypes = [vp, vp, vp, sz, vp]
+    lib.pt_debug_set_stamps.argtypes = [vp]
     lib.pt_attention_cl.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
@@ -69,7 +92,11 @@ EXPORTS = [
     "pt_refiner_workspace_bytes", "pt_refiner_forward", "pt_interp_blend", "pt_conv1d_cl", "pt_ncl_to_cl",
     "pt_cl_to_ncl", "pt_pq_search_cl", "pt_pq_gather_cl", "pt_attention_cl", "pt_gemm_bf16", "pt_gemm_bf16_lnmod",
     "pt_gemm_bf16_addln", "pt_prof_enable",
-    "pt_prof_read",
+    "pt_prof_read", "pt_embed_pe", "pt_train_wgrad", "pt_train_colsum", "pt_train_ln_fwd", "pt_train_ln_bwd",
+    "pt_train_modsilu_fwd", "pt_train_modsilu_bwd", "pt_train_attention_fwd", "pt_train_attention_bwd",
+    "pt_train_cross_entropy", "pt_train_bn_fwd", "pt_train_bn_bwd", "pt_train_act_bwd", "pt_train_gate_fwd",
+    "pt_train_gate_bwd", "pt_train_embed_bwd", "pt_train_dropout", "pt_train_sumsq", "pt_train_clip_coef",
+    "pt_train_adamw", "pt_train_add", "pt_debug_set_stamps",
 ]
 
 

@@ -11,6 +11,30 @@ struct pt_model {
   Model m;
 };
 
+namespace pt {
+int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int N, int Cin, int kind, int B, int Lin, hipStream_t s);
+int launch_colsum(const float* a, int lda, const float* b, int ldb, int rows, int cols, float* out, hipStream_t s);
+int launch_ln_fwd(const float* x, const float* res, const float* g, const float* b, float* y, float* stats, int rows, hipStream_t s);
+int launch_ln_bwd(const float* dy, const float* x, const float* res, const float* stats, const float* g, float* dx, float* dg, float* db, int rows, hipStream_t s);
+int launch_modsilu_fwd(const float* y, const float* table, const int64_t* label, int n_label, int rows_per_clip, int n_classes, float* h, int rows, hipStream_t s);
+int launch_modsilu_bwd(const float* dh, const float* y, const float* table, const int64_t* label, int n_label, int rows_per_clip, int n_classes, float* dy, float* dtable, int rows, hipStream_t s);
+int launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* dO, int ldo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, float* lse, float* delta, int B, int Nq, int Nk, int H, float pdrop, unsigned long long seed, hipStream_t s);
+int launch_attention_train_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B, int Nq, int Nk, int H, float pdrop, unsigned long long seed, hipStream_t s);
+int launch_ce(const float* logits, const int64_t* target, int V, int rows, float* loss, float* dlogits, hipStream_t s);
+int launch_bn_train_fwd(const float* x, int ldx, int rows, int cols, const float* g, const float* b, const float* res, int ldr, float slope, float* y, int ldy, float* mean_rstd, double* acc_ws, float* run_mean, float* run_var, float momentum, hipStream_t s);
+int launch_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy, float slope, const float* x, int ldx, const float* mean_rstd, const float* g, float* dz, int lddz, float* dx, int lddx, float* sums, int rows, int cols, hipStream_t s);
+int launch_act_bwd(const float* dy, int lddy, const float* y, int ldy, float slope, float* dz, int lddz, int rows, int cols, hipStream_t s);
+int launch_gate_fwd(const float* hv, int rows, int C, float* out, hipStream_t s);
+int launch_gate_bwd(const float* dout, const float* hv, int rows, int C, float* dhv, hipStream_t s);
+int launch_embed_bwd(const float* dx, const int* ids, int rows, int vocab, float* dE, hipStream_t s);
+int launch_dropout(const float* x, float* y, size_t n, float p, unsigned long long seed, hipStream_t s);
+int launch_sumsq(const float* g, size_t n, float* out, hipStream_t s);
+int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* gscale, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t s);
+int launch_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, hipStream_t s);
+int launch_add(const float* a, const float* b, float* out, size_t n, hipStream_t s);
+int launch_embed_pe(const int* ids, const float* tok, const double* pe, const double* ppe, float* x, unsigned short* xb, int rows, int N, int G, int vocab, hipStream_t s);
+}  // namespace pt
+
 extern "C" {
 
 const char* pt_last_error(void) { return last_error(); }
@@ -252,4 +276,78 @@ int pt_pq_gather_cl(const void* idx, int idx_are_int64, const float* codebooks, 
   return launch_pq_gather(idx, idx_are_int64, codebooks, rows, G, D, K, out, ldq, G * D, (hipStream_t)stream);
 }
 
+/* ---- training-mode op-level entry points (train.hip) ---- */
+int pt_embed_pe(const int32_t* ids, const float* tok, const double* pe, const double* ppe, float* x, int rows, int N, int G,
+                int vocab, void* stream) {
+  PT_CHECK(ids && tok && pe && ppe && x && rows > 0 && N > 0 && G > 0, "pt_embed_pe: bad argument");
+  return launch_embed_pe(ids, tok, pe, ppe, x, nullptr, rows, N, G, vocab, (hipStream_t)stream);
+}
+int pt_train_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int N, int Cin, int kind, int B, int Lin,
+                   void* stream) { return launch_wgrad(dY, lddy, X, ldx, dW, N, Cin, kind, B, Lin, (hipStream_t)stream); }
+int pt_train_colsum(const float* a, int lda, const float* b, int ldb, int rows, int cols, float* out, void* stream) {
+  return launch_colsum(a, lda, b, ldb, rows, cols, out, (hipStream_t)stream);
+}
+int pt_train_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y, float* stats, int rows,
+                    void* stream) { return launch_ln_fwd(x, res, gamma, beta, y, stats, rows, (hipStream_t)stream); }
+int pt_train_ln_bwd(const float* dy, const float* x, const float* res, const float* stats, const float* gamma, float* dx,
+                    float* dgamma, float* dbeta, int rows, void* stream) {
+  return launch_ln_bwd(dy, x, res, stats, gamma, dx, dgamma, dbeta, rows, (hipStream_t)stream);
+}
+int pt_train_modsilu_fwd(const float* y, const float* table, const int64_t* label, int n_label, int rows_per_clip, int n_classes,
+                         float* h, int rows, void* stream) {
+  return launch_modsilu_fwd(y, table, label, n_label, rows_per_clip, n_classes, h, rows, (hipStream_t)stream);
+}
+int pt_train_modsilu_bwd(const float* dh, const float* y, const float* table, const int64_t* label, int n_label,
+                         int rows_per_clip, int n_classes, float* dy, float* dtable, int rows, void* stream) {
+  return launch_modsilu_bwd(dh, y, table, label, n_label, rows_per_clip, n_classes, dy, dtable, rows, (hipStream_t)stream);
+}
+int pt_train_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* dO, int ldo,
+                           float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, float* lse, float* delta, int B,
+                           int Nq, int Nk, int H, float pdrop, uint64_t seed, void* stream) {
+  return launch_attention_bwd(Q, ldq, K, ldk, V, ldv, dO, ldo, dQ, lddq, dK, lddk, dV, lddv, lse, delta, B, Nq, Nk, H, pdrop,
+                              seed, (hipStream_t)stream);
+}
+int pt_train_attention_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,
+                           int Nq, int Nk, int H, float pdrop, uint64_t seed, void* stream) {
+  return launch_attention_train_fwd(Q, ldq, K, ldk, V, ldv, O, ldo, B, Nq, Nk, H, pdrop, seed, (hipStream_t)stream);
+}
+int pt_train_cross_entropy(const float* logits, const int64_t* target, int V, int rows, float* loss, float* dlogits,
+                           void* stream) { return launch_ce(logits, target, V, rows, loss, dlogits, (hipStream_t)stream); }
+int pt_train_bn_fwd(const float* x, int ldx, int rows, int cols, const float* gamma, const float* beta, const float* res, int ldr,
+                    float slope, float* y, int ldy, float* mean_rstd, double* acc_ws, float* run_mean, float* run_var,
+                    float momentum, void* stream) {
+  return launch_bn_train_fwd(x, ldx, rows, cols, gamma, beta, res, ldr, slope, y, ldy, mean_rstd, acc_ws, run_mean, run_var,
+                             momentum, (hipStream_t)stream);
+}
+int pt_train_bn_bwd(const float* dy, int lddy, const float* y, int ldy, float slope, const float* x, int ldx,
+                    const float* mean_rstd, const float* gamma, float* dz, int lddz, float* dx, int lddx, float* sums, int rows,
+                    int cols, void* stream) {
+  return launch_bn_train_bwd(dy, lddy, y, ldy, slope, x, ldx, mean_rstd, gamma, dz, lddz, dx, lddx, sums, rows, cols,
+                             (hipStream_t)stream);
+}
+int pt_train_act_bwd(const float* dy, int lddy, const float* y, int ldy, float slope, float* dz, int lddz, int rows, int cols,
+                     void* stream) { return launch_act_bwd(dy, lddy, y, ldy, slope, dz, lddz, rows, cols, (hipStream_t)stream); }
+int pt_train_gate_fwd(const float* hv, int rows, int C, float* out, void* stream) {
+  return launch_gate_fwd(hv, rows, C, out, (hipStream_t)stream);
+}
+int pt_train_gate_bwd(const float* dout, const float* hv, int rows, int C, float* dhv, void* stream) {
+  return launch_gate_bwd(dout, hv, rows, C, dhv, (hipStream_t)stream);
+}
+int pt_train_embed_bwd(const float* dx, const int32_t* ids, int rows, int vocab, float* dE, void* stream) {
+  return launch_embed_bwd(dx, ids, rows, vocab, dE, (hipStream_t)stream);
+}
+int pt_train_dropout(const float* x, float* y, size_t n, float p, uint64_t seed, void* stream) {
+  return launch_dropout(x, y, n, p, seed, (hipStream_t)stream);
+}
+int pt_train_sumsq(const float* g, size_t n, float* out, void* stream) { return launch_sumsq(g, n, out, (hipStream_t)stream); }
+int pt_train_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream) {
+  return launch_clip_coef(sumsq, max_norm, coef, norm_out, (hipStream_t)stream);
+}
+int pt_train_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* gscale, float lr, float beta1,
+                   float beta2, float eps, float wd, int step, void* stream) {
+  return launch_adamw(p, g, m, v, n, gscale, lr, beta1, beta2, eps, wd, step, (hipStream_t)stream);
+}
+int pt_train_add(const float* a, const float* b, float* out, size_t n, void* stream) {
+  return launch_add(a, b, out, n, (hipStream_t)stream);
+}
 }  // extern "C"

@@ -1,0 +1,787 @@
+// Training-mode kernels of the predictor path (fp32): weight/bias gradients of the tap-GEMM, LayerNorm and the
+// stylization modulate+SiLU forward/backward, attention backward, cross-entropy, train-mode BatchNorm statistics and
+// application, gate / activation derivatives, embedding gradient, dropout, gradient norm and AdamW.
+// The forward GEMMs and the input-gradient GEMMs are the inference tap-GEMM (gemm.hip) fed with re-laid-out weights:
+//   dX of Linear / stride-1 conv = tap-GEMM of dY with W^T per tap and negated tap offsets,
+//   dX of the k4 s2 conv         = the ConvTranspose form (two output parities x two taps) with W^T per tap,
+//   dX of the k4 s2 transposed conv = the k4 s2 conv form.
+// Reference lines: predictor.py:168-280 (train step), PTransformer.py:443-504 (train forward), 28-165 (style block),
+// vqvae_modules.py:107-200 (ConvNormRelu with batch statistics), torch.optim.AdamW, torch.nn.utils.clip_grad_norm_.
+#include <cmath>
+#include <cstring>
+
+#include "pt_common.h"
+
+namespace pt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int DM = 512;
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+__device__ __forceinline__ unsigned mix32(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (unsigned)((z ^ (z >> 31)) >> 32);
+}
+// dropout keep-factor of attention weight (b,h,i,j): 0 or 1/(1-p), from a counter-based hash (replayed in backward)
+__device__ __forceinline__ float attn_keep(unsigned long long seed, size_t idx, unsigned thr, float keep_scale) {
+  return mix32(seed * 0x100000001B3ull + idx) >= thr ? keep_scale : 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// Weight gradient of the tap-GEMM: dW[t][n][c] += sum_m dY[orow(m)][n] * X[src(m,t)][c]
+// (v_mfma_f32_32x32x2_f32 with the GEMM row index m as the contraction: both operands are read row-major).
+// Workgroup = 128 (n) x 128 (c) tile of one tap over one slice of m; slices are combined with fp32 atomics.
+// ---------------------------------------------------------------------------
+struct WgradArgs {
+  const float* dY; int lddy;     // [B*Lout, lddy]
+  const float* X;  int ldx;      // [B*Lin, ldx]
+  float* dW;                     // [ntaps][N][Cin] (row-major, reference layout after a permute), pre-zeroed
+  int N, Cin, ntaps;
+  int tap_d[MAX_TAPS];
+  int M, Lgrid, Lin, Lout, in_stride, out_stride, out_off;
+  int msplit;
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, int tiles_n, int tiles_c) {
+  constexpr int MK = 16, LDSW = 132;
+  __shared__ __attribute__((aligned(16))) float ys[MK][LDSW];
+  __shared__ __attribute__((aligned(16))) float xs[MK][LDSW];
+  int bid = blockIdx.x;
+  const int ms = bid % p.msplit; bid /= p.msplit;
+  const int tc = bid % tiles_c; bid /= tiles_c;
+  const int tn = bid % tiles_n; bid /= tiles_n;
+  const int tap = bid;
+  const int n0 = tn * 128, c0 = tc * 128, d = p.tap_d[tap];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave >> 1, wc = wave & 1;
+  const int chunk = ((p.M + p.msplit - 1) / p.msplit + MK - 1) / MK * MK;
+  const int m_begin = ms * chunk, m_end = min(p.M, m_begin + chunk);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  const bool plain = (p.out_stride == 1 && p.out_off == 0 && p.Lgrid == p.Lout && p.in_stride == 1 && p.Lin == p.Lgrid);
+  for (int mb = m_begin; mb < m_end; mb += MK) {
+    // stage MK rows of dY (columns n0..) and of the tap-shifted X (columns c0..): 2 x float4 per thread per operand
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 256 * i, row = e >> 5, c4 = (e & 31) * 4;
+      const int m = mb + row;
+      f32x4 yv = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end) {
+        int orow = m, l, b;
+        if (plain) { b = m / p.Lgrid; l = m - b * p.Lgrid; }
+        else { b = m / p.Lgrid; l = m - b * p.Lgrid; orow = b * p.Lout + l * p.out_stride + p.out_off; }
+        const int ls = l * p.in_stride + d;
+        if (n0 + c4 < p.N) {
+          const float* yp = p.dY + (size_t)orow * p.lddy + n0 + c4;
+          if (n0 + c4 + 3 < p.N) yv = *reinterpret_cast<const f32x4*>(yp);
+          else for (int k = 0; k < 4; ++k) if (n0 + c4 + k < p.N) yv[k] = yp[k];
+        }
+        if ((unsigned)ls < (unsigned)p.Lin && c0 + c4 < p.Cin) {
+          const float* xp = p.X + (size_t)(b * p.Lin + ls) * p.ldx + c0 + c4;
+          if (c0 + c4 + 3 < p.Cin) xv = *reinterpret_cast<const f32x4*>(xp);
+          else for (int k = 0; k < 4; ++k) if (c0 + c4 + k < p.Cin) xv[k] = xp[k];
+        }
+      }
+      *reinterpret_cast<f32x4*>(&ys[row][c4]) = yv;
+      *reinterpret_cast<f32x4*>(&xs[row][c4]) = xv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k2 = 0; k2 < MK / 2; ++k2) {
+      const int mr = 2 * k2 + (lane >> 5);
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = ys[mr][wn * 64 + i * 32 + (lane & 31)];
+        b[i] = xs[mr][wc * 64 + i * 32 + (lane & 31)];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D[i = n][j = c]: lane&31 = c, registers = n rows
+  float* out = p.dW + (size_t)tap * p.N * p.Cin;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + wc * 64 + j * 32 + (lane & 31);
+      if (c >= p.Cin) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n < p.N) atomicAdd(out + (size_t)n * p.Cin + c, acc[i][j][r]);
+      }
+    }
+}
+
+int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int N, int Cin, int kind, int B, int Lin,
+                 hipStream_t s) {
+  PT_CHECK(dY && X && dW && N > 0 && Cin > 0 && B > 0 && Lin > 0, "wgrad: bad argument");
+  PT_CHECK(lddy % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0, "wgrad: rows must be 16-byte aligned");
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dY = dY; a.lddy = lddy; a.X = X; a.ldx = ldx; a.dW = dW; a.N = N; a.Cin = Cin;
+  a.Lin = Lin; a.in_stride = 1; a.out_stride = 1; a.out_off = 0;
+  int launches = 1;
+  switch (kind) {
+    case 0: a.ntaps = 1; a.Lgrid = a.Lout = Lin; break;
+    case 1: a.ntaps = 3; for (int k = 0; k < 3; ++k) a.tap_d[k] = k - 1; a.Lgrid = a.Lout = Lin; break;
+    case 2: a.ntaps = 7; for (int k = 0; k < 7; ++k) a.tap_d[k] = k - 3; a.Lgrid = a.Lout = Lin; break;
+    case 3: a.ntaps = 4; for (int k = 0; k < 4; ++k) a.tap_d[k] = k - 1; a.in_stride = 2; a.Lgrid = a.Lout = (Lin - 2) / 2 + 1; break;
+    case 4: launches = 2; a.ntaps = 4; a.Lgrid = Lin; a.Lout = 2 * Lin; a.out_stride = 2; break;
+    default: PT_CHECK(false, "wgrad: kind %d unknown", kind);
+  }
+  a.M = B * a.Lgrid;
+  const int tiles_n = (N + 127) / 128, tiles_c = (Cin + 127) / 128;
+  for (int par = 0; par < launches; ++par) {
+    if (kind == 4) {
+      // ConvTranspose1d k4 s2 p1: out[2q] = x[q] w1 + x[q-1] w3 ; out[2q+1] = x[q] w2 + x[q+1] w0.  Taps not of this
+      // output parity get an offset that never lands in range, so they contribute nothing.
+      const int far = 1 << 28;
+      a.out_off = par;
+      if (par == 0) { a.tap_d[0] = far; a.tap_d[1] = 0; a.tap_d[2] = far; a.tap_d[3] = -1; }
+      else { a.tap_d[0] = 1; a.tap_d[1] = far; a.tap_d[2] = 0; a.tap_d[3] = far; }
+    }
+    const int base = tiles_n * tiles_c * a.ntaps;
+    int msplit = (1024 + base - 1) / base;
+    const int maxsplit = (a.M + 63) / 64;
+    if (msplit > maxsplit) msplit = maxsplit;
+    if (msplit < 1) msplit = 1;
+    a.msplit = msplit;
+    PT_LAUNCH(wgrad_kernel, dim3(base * msplit), dim3(256), 0, s, a, tiles_n, tiles_c);
+  }
+  return 0;
+}
+
+// column sums: out[c] += sum_rows a[row][c] (* b[row][c] when b != null)   (bias / BatchNorm / LayerNorm-affine gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b,
+                                                     int ldb, int rows, int cols, float* __restrict__ out, int rows_per_block) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  double s = 0.0;
+  if (c < cols)
+    for (int r = r0 + sub; r < r1; r += 4) {
+      const float v = a[(size_t)r * lda + c];
+      s += b ? (double)v * (double)b[(size_t)r * ldb + c] : (double)v;
+    }
+  __shared__ double red[4][64];
+  red[sub][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sub == 0 && c < cols) atomicAdd(out + c, (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+int launch_colsum(const float* a, int lda, const float* b, int ldb, int rows, int cols, float* out, hipStream_t s) {
+  PT_CHECK(a && out && rows > 0 && cols > 0, "colsum: bad argument");
+  const int rpb = 256;
+  PT_LAUNCH(colsum_kernel, dim3((cols + 63) / 64, (rows + rpb - 1) / rpb), dim3(256), 0, s, a, lda, b, ldb, rows, cols, out, rpb);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm over 512-wide rows, one wave per row.  fwd saves mean / rstd; bwd accumulates dgamma / dbeta.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                     const float* __restrict__ g, const float* __restrict__ b,
+                                                     float* __restrict__ y, float* __restrict__ stats, int rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = (i >> 2) * 256 + lane * 4 + (i & 3);
+    v[i] = x[(size_t)row * DM + c] + (res ? res[(size_t)row * DM + c] : 0.f);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += v[i];
+  const float mean = wsum(s) * (1.f / DM);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q += (v[i] - mean) * (v[i] - mean);
+  const float rstd = 1.0f / sqrtf(wsum(q) * (1.f / DM) + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = (i >> 2) * 256 + lane * 4 + (i & 3);
+    y[(size_t)row * DM + c] = (v[i] - mean) * rstd * g[c] + b[c];
+  }
+  if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+// xin = the LayerNorm INPUT (x + res of the forward); dx = gradient w.r.t. that input
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ res, const float* __restrict__ stats,
+                                                     const float* __restrict__ g, float* __restrict__ dx,
+                                                     float* __restrict__ dg, float* __restrict__ db, int rows, int rows_per_wave) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float ag[8], ab[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+  const int r0 = w * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
+  for (int row = r0; row < r1; ++row) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float xh[8], gd[8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = (i >> 2) * 256 + lane * 4 + (i & 3);
+      const float xv = x[(size_t)row * DM + c] + (res ? res[(size_t)row * DM + c] : 0.f);
+      const float d = dy[(size_t)row * DM + c];
+      xh[i] = (xv - mean) * rstd;
+      gd[i] = d * g[c];
+      ag[i] += d * xh[i];
+      ab[i] += d;
+      s1 += gd[i];
+      s2 += gd[i] * xh[i];
+    }
+    s1 = wsum(s1) * (1.f / DM);
+    s2 = wsum(s2) * (1.f / DM);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = (i >> 2) * 256 + lane * 4 + (i & 3);
+      dx[(size_t)row * DM + c] = rstd * (gd[i] - s1 - xh[i] * s2);
+    }
+  }
+  if (r0 < r1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = (i >> 2) * 256 + lane * 4 + (i & 3);
+      atomicAdd(dg + c, ag[i]);
+      atomicAdd(db + c, ab[i]);
+    }
+  }
+}
+int launch_ln_fwd(const float* x, const float* res, const float* g, const float* b, float* y, float* stats, int rows,
+                  hipStream_t s) {
+  PT_CHECK(x && g && b && y && stats && rows > 0, "ln_fwd: bad argument");
+  PT_LAUNCH(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, res, g, b, y, stats, rows);
+  return 0;
+}
+int launch_ln_bwd(const float* dy, const float* x, const float* res, const float* stats, const float* g, float* dx,
+                  float* dg, float* db, int rows, hipStream_t s) {
+  PT_CHECK(dy && x && stats && g && dx && dg && db && rows > 0, "ln_bwd: bad argument");
+  const int rpw = 16, waves = (rows + rpw - 1) / rpw;
+  PT_LAUNCH(ln_bwd_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, dy, x, res, stats, g, dx, dg, db, rows, rpw);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// stylization modulate + SiLU (PTransformer.py:134-139): h = SiLU(y * (1 + scale[c]) + shift[c]), c = label of the row's clip.
+// table [n_classes][1024] = scale | shift.  bwd: dy, dtable (per-class sums, flushed when the class changes).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void modsilu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ table,
+                                                          const int64_t* __restrict__ label, int n_label, int rows_per_clip,
+                                                          int n_classes, float* __restrict__ h, int rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  long long lb = label[n_label == 1 ? 0 : row / rows_per_clip];
+  lb = lb < 0 ? 0 : (lb >= n_classes ? n_classes - 1 : lb);
+  const float* t = table + (size_t)lb * 2 * DM;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = (i >> 2) * 256 + lane * 4 + (i & 3);
+    const float u = y[(size_t)row * DM + c] * (1.f + t[c]) + t[DM + c];
+    h[(size_t)row * DM + c] = u / (1.f + expf(-u));
+  }
+}
+__global__ __launch_bounds__(256) void modsilu_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ y,
+                                                          const float* __restrict__ table, const int64_t* __restrict__ label,
+                                                          int n_label, int rows_per_clip, int n_classes,
+                                                          float* __restrict__ dy, float* __restrict__ dtable, int rows,
+                                                          int rows_per_wave) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int r0 = w * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
+  float asc[8], ash[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { asc[i] = 0.f; ash[i] = 0.f; }
+  long long cur = -1;
+  auto flush = [&]() {
+    if (cur < 0) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = (i >> 2) * 256 + lane * 4 + (i & 3);
+      atomicAdd(dtable + (size_t)cur * 2 * DM + c, asc[i]);
+      atomicAdd(dtable + (size_t)cur * 2 * DM + DM + c, ash[i]);
+      asc[i] = 0.f; ash[i] = 0.f;
+    }
+  };
+  for (int row = r0; row < r1; ++row) {
+    long long lb = label[n_label == 1 ? 0 : row / rows_per_clip];
+    lb = lb < 0 ? 0 : (lb >= n_classes ? n_classes - 1 : lb);
+    if (lb != cur) { flush(); cur = lb; }
+    const float* t = table + (size_t)lb * 2 * DM;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = (i >> 2) * 256 + lane * 4 + (i & 3);
+      const float yv = y[(size_t)row * DM + c], sc = 1.f + t[c];
+      const float u = yv * sc + t[DM + c];
+      const float sg = 1.f / (1.f + expf(-u));
+      const float du = dh[(size_t)row * DM + c] * (sg * (1.f + u * (1.f - sg)));
+      dy[(size_t)row * DM + c] = du * sc;
+      asc[i] += du * yv;
+      ash[i] += du;
+    }
+  }
+  flush();
+}
+int launch_modsilu_fwd(const float* y, const float* table, const int64_t* label, int n_label, int rows_per_clip,
+                       int n_classes, float* h, int rows, hipStream_t s) {
+  PT_CHECK(y && table && label && h && rows > 0 && rows_per_clip > 0, "modsilu_fwd: bad argument");
+  PT_LAUNCH(modsilu_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, y, table, label, n_label, rows_per_clip, n_classes, h, rows);
+  return 0;
+}
+int launch_modsilu_bwd(const float* dh, const float* y, const float* table, const int64_t* label, int n_label,
+                       int rows_per_clip, int n_classes, float* dy, float* dtable, int rows, hipStream_t s) {
+  PT_CHECK(dh && y && table && label && dy && dtable && rows > 0 && rows_per_clip > 0, "modsilu_bwd: bad argument");
+  const int rpw = 16, waves = (rows + rpw - 1) / rpw;
+  PT_LAUNCH(modsilu_bwd_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, dh, y, table, label, n_label, rows_per_clip,
+            n_classes, dy, dtable, rows, rpw);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// attention backward (head dim 64, no mask, optional dropout-free): recomputes the probabilities.
+//   pass Q: one wave per query row -> dQ row, lse, delta = dO . O
+//   pass KV: one wave per key row  -> dK, dV rows (no atomics)
+// rows are b*N + i, head h at column h*64 (same addressing as pt_attention_cl).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
+                                                         int ldk, const float* __restrict__ V, int ldv,
+                                                         const float* __restrict__ dO, int ldo, float* __restrict__ dQ,
+                                                         int lddq, float* __restrict__ lse, float* __restrict__ delta,
+                                                         int B, int Nq, int Nk, int H, float scale, float pdrop,
+                                                         unsigned long long seed) {
+  extern __shared__ float sm[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* sc = sm + wave * 2 * Nk;     // scores, then probabilities
+  float* dp = sc + Nk;
+  const int gw = blockIdx.x * 4 + wave;
+  if (gw >= B * H * Nq) return;
+  const int i = gw % Nq, h = (gw / Nq) % H, b = gw / (Nq * H);
+  const float q = Q[(size_t)(b * Nq + i) * ldq + h * 64 + lane];
+  const float go = dO[(size_t)(b * Nq + i) * ldo + h * 64 + lane];
+  const unsigned thr = (unsigned)((double)pdrop * 4294967296.0);
+  const float ks = 1.f / (1.f - pdrop);
+  const size_t mbase = ((size_t)(b * H + h) * Nq + i) * Nk;
+  float mx = -INFINITY;
+  for (int j = 0; j < Nk; ++j) {
+    const float s = wsum(q * K[(size_t)(b * Nk + j) * ldk + h * 64 + lane]) * scale;
+    float d = wsum(go * V[(size_t)(b * Nk + j) * ldv + h * 64 + lane]);
+    if (pdrop > 0.f) d *= attn_keep(seed, mbase + j, thr, ks);     // dA = dAd * mask / (1-p)
+    if (lane == 0) { sc[j] = s; dp[j] = d; }
+    mx = fmaxf(mx, s);
+  }
+  float l = 0.f;
+  for (int j = lane; j < Nk; j += 64) l += expf(sc[j] - mx);
+  l = wsum(l);
+  const float ls = mx + logf(l);
+  float dl = 0.f;
+  for (int j = lane; j < Nk; j += 64) dl += expf(sc[j] - ls) * dp[j];
+  dl = wsum(dl);
+  float dq = 0.f;
+  for (int j = 0; j < Nk; ++j) {
+    const float pj = expf(sc[j] - ls);
+    dq += pj * (dp[j] - dl) * scale * K[(size_t)(b * Nk + j) * ldk + h * 64 + lane];
+  }
+  dQ[(size_t)(b * Nq + i) * lddq + h * 64 + lane] = dq;
+  if (lane == 0) { lse[(size_t)(b * H + h) * Nq + i] = ls; delta[(size_t)(b * H + h) * Nq + i] = dl; }
+}
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
+                                                          int ldk, const float* __restrict__ V, int ldv,
+                                                          const float* __restrict__ dO, int ldo, const float* __restrict__ lse,
+                                                          const float* __restrict__ delta, float* __restrict__ dK, int lddk,
+                                                          float* __restrict__ dV, int lddv, int B, int Nq, int Nk, int H,
+                                                          float scale, float pdrop, unsigned long long seed) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + wave;
+  if (gw >= B * H * Nk) return;
+  const int j = gw % Nk, h = (gw / Nk) % H, b = gw / (Nk * H);
+  const float k = K[(size_t)(b * Nk + j) * ldk + h * 64 + lane];
+  const float v = V[(size_t)(b * Nk + j) * ldv + h * 64 + lane];
+  float dk = 0.f, dv = 0.f;
+  const unsigned thr = (unsigned)((double)pdrop * 4294967296.0);
+  const float ks = 1.f / (1.f - pdrop);
+  for (int i = 0; i < Nq; ++i) {
+    const float q = Q[(size_t)(b * Nq + i) * ldq + h * 64 + lane];
+    const float go = dO[(size_t)(b * Nq + i) * ldo + h * 64 + lane];
+    const float s = wsum(q * k) * scale;
+    float d = wsum(go * v);
+    const float p = expf(s - lse[(size_t)(b * H + h) * Nq + i]);
+    const float keep = pdrop > 0.f ? attn_keep(seed, ((size_t)(b * H + h) * Nq + i) * Nk + j, thr, ks) : 1.f;
+    d *= keep;
+    dv += p * keep * go;
+    dk += p * (d - delta[(size_t)(b * H + h) * Nq + i]) * scale * q;
+  }
+  dK[(size_t)(b * Nk + j) * lddk + h * 64 + lane] = dk;
+  dV[(size_t)(b * Nk + j) * lddv + h * 64 + lane] = dv;
+}
+// forward with dropout on the attention weights (nn.MultiheadAttention(dropout=0.1) in train mode): one wave per query row
+__global__ __launch_bounds__(256) void attn_fwd_train_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
+                                                             int ldk, const float* __restrict__ V, int ldv, float* __restrict__ O,
+                                                             int ldo, int B, int Nq, int Nk, int H, float scale, float pdrop,
+                                                             unsigned long long seed) {
+  extern __shared__ float sm[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* sc = sm + wave * Nk;
+  const int gw = blockIdx.x * 4 + wave;
+  if (gw >= B * H * Nq) return;
+  const int i = gw % Nq, h = (gw / Nq) % H, b = gw / (Nq * H);
+  const float q = Q[(size_t)(b * Nq + i) * ldq + h * 64 + lane];
+  float mx = -INFINITY;
+  for (int j = 0; j < Nk; ++j) {
+    const float s = wsum(q * K[(size_t)(b * Nk + j) * ldk + h * 64 + lane]) * scale;
+    if (lane == 0) sc[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  float l = 0.f;
+  for (int j = lane; j < Nk; j += 64) l += expf(sc[j] - mx);
+  l = wsum(l);
+  const unsigned thr = (unsigned)((double)pdrop * 4294967296.0);
+  const float ks = 1.f / (1.f - pdrop);
+  const size_t mbase = ((size_t)(b * H + h) * Nq + i) * Nk;
+  float o = 0.f;
+  for (int j = 0; j < Nk; ++j)
+    o += expf(sc[j] - mx) / l * attn_keep(seed, mbase + j, thr, ks) * V[(size_t)(b * Nk + j) * ldv + h * 64 + lane];
+  O[(size_t)(b * Nq + i) * ldo + h * 64 + lane] = o;
+}
+int launch_attention_train_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,
+                               int Nq, int Nk, int H, float pdrop, unsigned long long seed, hipStream_t s) {
+  PT_CHECK(Q && K && V && O && B > 0 && Nq > 0 && Nk > 0 && H > 0 && pdrop >= 0.f && pdrop < 1.f, "attention_train_fwd: bad argument");
+  PT_CHECK(Nk <= 4096, "attention_train_fwd: %d keys exceed the per-wave score buffer", Nk);
+  PT_LAUNCH(attn_fwd_train_kernel, dim3((B * H * Nq + 3) / 4), dim3(256), (size_t)4 * Nk * sizeof(float), s, Q, ldq, K, ldk, V,
+            ldv, O, ldo, B, Nq, Nk, H, 0.125f, pdrop, seed);
+  return 0;
+}
+int launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* dO, int ldo,
+                         float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, float* lse, float* delta, int B,
+                         int Nq, int Nk, int H, float pdrop, unsigned long long seed, hipStream_t s) {
+  PT_CHECK(Q && K && V && dO && dQ && dK && dV && lse && delta && B > 0 && Nq > 0 && Nk > 0 && H > 0, "attention_bwd: bad argument");
+  PT_CHECK(Nk <= 2048, "attention_bwd: %d keys exceed the per-wave score buffer", Nk);
+  const size_t smem = (size_t)4 * 2 * Nk * sizeof(float);
+  PT_LAUNCH(attn_bwd_q_kernel, dim3((B * H * Nq + 3) / 4), dim3(256), smem, s, Q, ldq, K, ldk, V, ldv, dO, ldo, dQ, lddq, lse,
+            delta, B, Nq, Nk, H, 0.125f, pdrop, seed);
+  PT_LAUNCH(attn_bwd_kv_kernel, dim3((B * H * Nk + 3) / 4), dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, dO, ldo, lse, delta, dK,
+            lddk, dV, lddv, B, Nq, Nk, H, 0.125f, pdrop, seed);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// cross entropy over rows of V logits (F.cross_entropy, mean reduction): loss += (lse - logit[target]) / rows,
+// dlogits = (softmax - onehot) / rows.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, int V,
+                                                 int rows, float* __restrict__ loss, float* __restrict__ dlogits) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* lg = logits + (size_t)row * V;
+  float mx = -INFINITY;
+  for (int c = lane; c < V; c += 64) mx = fmaxf(mx, lg[c]);
+  mx = wmax(mx);
+  float l = 0.f;
+  for (int c = lane; c < V; c += 64) l += expf(lg[c] - mx);
+  l = wsum(l);
+  const float ls = mx + logf(l);
+  const int t = (int)target[row];
+  const float inv = 1.f / (float)rows;
+  for (int c = lane; c < V; c += 64)
+    dlogits[(size_t)row * V + c] = (expf(lg[c] - ls) - (c == t ? 1.f : 0.f)) * inv;
+  if (lane == 0) atomicAdd(loss, (ls - lg[t]) * inv);
+}
+int launch_ce(const float* logits, const int64_t* target, int V, int rows, float* loss, float* dlogits, hipStream_t s) {
+  PT_CHECK(logits && target && loss && dlogits && V > 0 && rows > 0, "cross_entropy: bad argument");
+  PT_LAUNCH(ce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, logits, target, V, rows, loss, dlogits);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// train-mode BatchNorm1d on channels-last rows (vqvae_modules.py:193-200 in train mode):
+//   stats: per column mean and biased variance over the rows (fp64 accumulation), running-stat update;
+//   apply: y = act((x - mean) * rstd * g + b (+ res));  bwd: dx, dgamma, dbeta (+ dres = gradient through act).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int ldx, int rows, int cols,
+                                                       double* __restrict__ acc /* [2][cols] */, int rows_per_block) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  double s = 0.0, q = 0.0;
+  if (c < cols)
+    for (int r = r0 + sub; r < r1; r += 4) {
+      const double v = x[(size_t)r * ldx + c];
+      s += v; q += v * v;
+    }
+  __shared__ double red[2][4][64];
+  red[0][sub][threadIdx.x & 63] = s;
+  red[1][sub][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (sub == 0 && c < cols) {
+    atomicAdd(acc + c, red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
+    atomicAdd(acc + cols + c, red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
+  }
+}
+__global__ void bn_finish_kernel(const double* __restrict__ acc, int rows, int cols, float* __restrict__ mean_rstd /* [2][cols] */,
+                                 float* __restrict__ run_mean, float* __restrict__ run_var, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  const double m = acc[c] / rows;
+  double var = acc[cols + c] / rows - m * m;
+  var = var < 0 ? 0 : var;
+  mean_rstd[c] = (float)m;
+  mean_rstd[cols + c] = (float)(1.0 / sqrt(var + 1e-5));
+  if (run_mean) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+    const double unb = rows > 1 ? var * rows / (rows - 1) : var;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+  }
+}
+// act: slope < 0 -> none; slope >= 0 -> leaky relu with that slope (0 = relu)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ mean_rstd,
+                                                       const float* __restrict__ g, const float* __restrict__ b,
+                                                       const float* __restrict__ res, int ldr, float slope,
+                                                       float* __restrict__ y, int ldy, int rows, int cols) {
+  const size_t total = (size_t)rows * cols;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int r = (int)(e / cols), c = (int)(e - (size_t)r * cols);
+    float v = (x[(size_t)r * ldx + c] - mean_rstd[c]) * mean_rstd[cols + c] * g[c] + b[c];
+    if (res) v += res[(size_t)r * ldr + c];
+    if (slope >= 0.f) v = v > 0.f ? v : v * slope;
+    y[(size_t)r * ldy + c] = v;
+  }
+}
+// dz = dy * act'(y) (gradient at the pre-activation sum BN(x) + res): written to dz (also the residual's gradient)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
+                                                      float slope, float* __restrict__ dz, int lddz, int rows, int cols) {
+  const size_t total = (size_t)rows * cols;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int r = (int)(e / cols), c = (int)(e - (size_t)r * cols);
+    const float d = dy[(size_t)r * lddy + c];
+    dz[(size_t)r * lddz + c] = (slope < 0.f || y[(size_t)r * ldy + c] > 0.f) ? d : d * slope;
+  }
+}
+// dx = g * rstd * (dz - mean(dz) - xhat * mean(dz * xhat)); sums = [sum dz | sum dz*xhat] per column (from colsum passes)
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ x, int ldx,
+                                                     const float* __restrict__ mean_rstd, const float* __restrict__ g,
+                                                     const float* __restrict__ sums, float* __restrict__ dx, int lddx, int rows,
+                                                     int cols) {
+  const size_t total = (size_t)rows * cols;
+  const float inv = 1.f / (float)rows;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int r = (int)(e / cols), c = (int)(e - (size_t)r * cols);
+    const float rstd = mean_rstd[cols + c];
+    const float xh = (x[(size_t)r * ldx + c] - mean_rstd[c]) * rstd;
+    dx[(size_t)r * lddx + c] = g[c] * rstd * (dz[(size_t)r * lddz + c] - sums[c] * inv - xh * sums[cols + c] * inv);
+  }
+}
+// dgamma needs sum dz * xhat: xhat is materialised on the fly: out[c] += sum_r dz * (x - mean) * rstd
+__global__ __launch_bounds__(256) void bn_dgamma_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ x, int ldx,
+                                                        const float* __restrict__ mean_rstd, int rows, int cols,
+                                                        float* __restrict__ sums /* [2][cols]: sum dz | sum dz*xhat */,
+                                                        int rows_per_block) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  double s = 0.0, q = 0.0;
+  if (c < cols) {
+    const float m = mean_rstd[c], rs = mean_rstd[cols + c];
+    for (int r = r0 + sub; r < r1; r += 4) {
+      const double d = dz[(size_t)r * lddz + c];
+      s += d;
+      q += d * (double)((x[(size_t)r * ldx + c] - m) * rs);
+    }
+  }
+  __shared__ double red[2][4][64];
+  red[0][sub][threadIdx.x & 63] = s;
+  red[1][sub][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (sub == 0 && c < cols) {
+    atomicAdd(sums + c, (float)(red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x]));
+    atomicAdd(sums + cols + c, (float)(red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x]));
+  }
+}
+static int ew_blocks(size_t total) {
+  size_t b = (total + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+int launch_bn_train_fwd(const float* x, int ldx, int rows, int cols, const float* g, const float* b, const float* res, int ldr,
+                        float slope, float* y, int ldy, float* mean_rstd, double* acc_ws, float* run_mean, float* run_var,
+                        float momentum, hipStream_t s) {
+  PT_CHECK(x && g && b && y && mean_rstd && acc_ws && rows > 0 && cols > 0, "bn_train_fwd: bad argument");
+  PT_HIP(hipMemsetAsync(acc_ws, 0, sizeof(double) * 2 * cols, s));
+  const int rpb = 256;
+  PT_LAUNCH(bn_stats_kernel, dim3((cols + 63) / 64, (rows + rpb - 1) / rpb), dim3(256), 0, s, x, ldx, rows, cols, acc_ws, rpb);
+  PT_LAUNCH(bn_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, acc_ws, rows, cols, mean_rstd, run_mean, run_var, momentum);
+  PT_LAUNCH(bn_apply_kernel, dim3(ew_blocks((size_t)rows * cols)), dim3(256), 0, s, x, ldx, mean_rstd, g, b, res, ldr, slope, y,
+            ldy, rows, cols);
+  return 0;
+}
+// dy: gradient of the block output y = act(BN(x) + res).  Outputs: dz (gradient before the activation = residual gradient),
+// dx, sums [2][cols] (= dbeta | dgamma, pre-zeroed by this call).
+int launch_bn_train_bwd(const float* dy, int lddy, const float* y, int ldy, float slope, const float* x, int ldx,
+                        const float* mean_rstd, const float* g, float* dz, int lddz, float* dx, int lddx, float* sums, int rows,
+                        int cols, hipStream_t s) {
+  PT_CHECK(dy && y && x && mean_rstd && g && dz && dx && sums && rows > 0 && cols > 0, "bn_train_bwd: bad argument");
+  PT_LAUNCH(act_bwd_kernel, dim3(ew_blocks((size_t)rows * cols)), dim3(256), 0, s, dy, lddy, y, ldy, slope, dz, lddz, rows, cols);
+  PT_HIP(hipMemsetAsync(sums, 0, sizeof(float) * 2 * cols, s));
+  const int rpb = 256;
+  PT_LAUNCH(bn_dgamma_kernel, dim3((cols + 63) / 64, (rows + rpb - 1) / rpb), dim3(256), 0, s, dz, lddz, x, ldx, mean_rstd, rows,
+            cols, sums, rpb);
+  PT_LAUNCH(bn_bwd_kernel, dim3(ew_blocks((size_t)rows * cols)), dim3(256), 0, s, dz, lddz, x, ldx, mean_rstd, g, sums, dx, lddx,
+            rows, cols);
+  return 0;
+}
+int launch_act_bwd(const float* dy, int lddy, const float* y, int ldy, float slope, float* dz, int lddz, int rows, int cols,
+                   hipStream_t s) {
+  PT_CHECK(dy && y && dz && rows > 0 && cols > 0, "act_bwd: bad argument");
+  PT_LAUNCH(act_bwd_kernel, dim3(ew_blocks((size_t)rows * cols)), dim3(256), 0, s, dy, lddy, y, ldy, slope, dz, lddz, rows, cols);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// gate of GatedConv (gated_pixelcnn_1d.py:74-76): out = tanh(a) * sigmoid(b), hv = [a | b] (rows of 2*C)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ hv, int C, float* __restrict__ out, size_t total) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t r = e / C; const int c = (int)(e - r * C);
+    const float a = hv[r * 2 * C + c], b = hv[r * 2 * C + C + c];
+    out[e] = tanhf(a) * (1.f / (1.f + expf(-b)));
+  }
+}
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ hv, int C,
+                                                       float* __restrict__ dhv, size_t total) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t r = e / C; const int c = (int)(e - r * C);
+    const float a = hv[r * 2 * C + c], b = hv[r * 2 * C + C + c];
+    const float t = tanhf(a), sg = 1.f / (1.f + expf(-b)), d = dout[e];
+    dhv[r * 2 * C + c] = d * sg * (1.f - t * t);
+    dhv[r * 2 * C + C + c] = d * t * sg * (1.f - sg);
+  }
+}
+int launch_gate_fwd(const float* hv, int rows, int C, float* out, hipStream_t s) {
+  PT_CHECK(hv && out && rows > 0 && C > 0, "gate_fwd: bad argument");
+  PT_LAUNCH(gate_fwd_kernel, dim3(ew_blocks((size_t)rows * C)), dim3(256), 0, s, hv, C, out, (size_t)rows * C);
+  return 0;
+}
+int launch_gate_bwd(const float* dout, const float* hv, int rows, int C, float* dhv, hipStream_t s) {
+  PT_CHECK(dout && hv && dhv && rows > 0 && C > 0, "gate_bwd: bad argument");
+  PT_LAUNCH(gate_bwd_kernel, dim3(ew_blocks((size_t)rows * C)), dim3(256), 0, s, dout, hv, C, dhv, (size_t)rows * C);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// token-embedding gradient: dE[id[row]] += dx[row]  (PTransformer.py:447; fp32 atomics)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, const int* __restrict__ ids, int rows,
+                                                        int vocab, float* __restrict__ dE) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  int id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = (i >> 2) * 256 + lane * 4 + (i & 3);
+    atomicAdd(dE + (size_t)id * DM + c, dx[(size_t)row * DM + c]);
+  }
+}
+int launch_embed_bwd(const float* dx, const int* ids, int rows, int vocab, float* dE, hipStream_t s) {
+  PT_CHECK(dx && ids && dE && rows > 0 && vocab > 0, "embed_bwd: bad argument");
+  PT_LAUNCH(embed_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dx, ids, rows, vocab, dE);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// dropout (train mode): mask from a counter-based hash of (seed, element); y = x * mask / (1-p).  The same call with
+// the same seed replays the mask for the backward pass (no mask tensor is stored).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float p,
+                                                      unsigned long long seed) {
+  const float keep_scale = 1.f / (1.f - p);
+  const unsigned thr = (unsigned)((double)p * 4294967296.0);
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256)
+    y[e] = mix32(seed * 0x100000001B3ull + e) >= thr ? x[e] * keep_scale : 0.f;
+}
+int launch_dropout(const float* x, float* y, size_t n, float p, unsigned long long seed, hipStream_t s) {
+  PT_CHECK(x && y && n > 0 && p >= 0.f && p < 1.f, "dropout: bad argument");
+  PT_LAUNCH(dropout_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, n, p, seed);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// optimizer: squared-norm accumulation, gradient scaling, AdamW (torch.optim.AdamW semantics, amsgrad off)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ out) {
+  float s = 0.f;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) s += g[e] * g[e];
+  s = wsum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+int launch_sumsq(const float* g, size_t n, float* out, hipStream_t s) {
+  PT_CHECK(g && out && n > 0, "sumsq: bad argument");
+  size_t b = (n + 1023) / 1024;
+  PT_LAUNCH(sumsq_kernel, dim3((unsigned)(b > 1024 ? 1024 : b)), dim3(256), 0, s, g, n, out);
+  return 0;
+}
+// p, m, v updated in place; the gradient is multiplied by *gscale (device scalar: the clip coefficient) first
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, size_t n, const float* __restrict__ gscale, float lr,
+                                                    float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt) {
+  const float gs = gscale ? *gscale : 1.f;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const float gr = g[e] * gs;
+    float pv = p[e] * (1.f - lr * wd);
+    const float mv = beta1 * m[e] + (1.f - beta1) * gr;
+    const float vv = beta2 * v[e] + (1.f - beta2) * gr * gr;
+    m[e] = mv; v[e] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pv -= (lr / bc1) * (mv / denom);
+    p[e] = pv;
+  }
+}
+int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* gscale, float lr, float beta1, float beta2,
+                 float eps, float wd, int step, hipStream_t s) {
+  PT_CHECK(p && g && m && v && n > 0 && step >= 1, "adamw: bad argument");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  PT_LAUNCH(adamw_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, p, g, m, v, n, gscale, lr, beta1, beta2, eps, wd, bc1, sqrtf(bc2));
+  return 0;
+}
+// clip coefficient of torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (sqrt(sumsq) + 1e-6)); norm_out = sqrt(sumsq)
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef, float* __restrict__ norm_out) {
+  const float nrm = sqrtf(*sumsq);
+  const float c = max_norm / (nrm + 1e-6f);
+  *coef = c < 1.f ? c : 1.f;
+  if (norm_out) *norm_out = nrm;
+}
+int launch_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, hipStream_t s) {
+  PT_CHECK(sumsq && coef, "clip_coef: bad argument");
+  PT_LAUNCH(clip_coef_kernel, dim3(1), dim3(1), 0, s, sumsq, max_norm, coef, norm_out);
+  return 0;
+}
+
+// out = a + b (row-major, equal shapes) and out *= scalar: the two elementwise ops the autograd glue needs
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) out[e] = a[e] + b[e];
+}
+int launch_add(const float* a, const float* b, float* out, size_t n, hipStream_t s) {
+  PT_CHECK(a && b && out && n > 0, "add: bad argument");
+  PT_LAUNCH(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, a, b, out, n);
+  return 0;
+}
+
+}  // namespace pt

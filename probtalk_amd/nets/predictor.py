@@ -1,9 +1,10 @@
 """`s2g_body_predictor` wrapper mirror (nets/inpainting/predictor.py:27-686), inference side."""
 import time
 
+import numpy as np
 import torch
-import torch.optim as optim
 
+from .. import train_ops, training
 from .base import TrainWrapperBaseClass, get_speaker_id
 from .modules import VQVAE_SC, ConditionEncoder
 from .transformer_modules import PredictorNet, interp_blend
@@ -51,13 +52,24 @@ class TrainWrapper(TrainWrapperBaseClass):
         self.VQ.load_state_dict(model_ckpt['generator']['VQ'])
         self.in_dim = in_dim
         self.discriminator = None
+        # data_utils/lower_body.py:43-63: the 135 upper-body / hand joints kept out of SMPL-X's 165, as 6-D pairs
+        fix = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 21, 22, 23, 24, 25, 26, 30, 31, 32, 33, 34, 35]
+        keep = [i for i in range(165) if i not in fix]
+        self.c_index = np.asarray([v for i in keep for v in (2 * i, 2 * i + 1)] if self.convert_to_6d else keep)
+        L = self.config.Data.pose.generate_length
+        self.random_mask = torch.zeros([L - 29, 1, L])                 # predictor.py:94-96
+        for i in range(self.random_mask.shape[0]):
+            self.random_mask[i, 0, i:(i + 30)] = 1
+        self.train_dropout = 0.1                                        # nn.TransformerDecoderLayer / ConditionEncoder dp
+        self._seeds = train_ops._Seeds(0)
         super().__init__(args, config)
 
     def to_parallel(self):
         pass  # one process per GPU: batch sharding lives in probtalk_amd.dist, not nn.DataParallel
 
     def init_optimizer(self):
-        self.generator_optimizer = optim.AdamW(
+        # torch.optim.AdamW semantics (predictor.py:112-118) on the library's HIP kernel
+        self.generator_optimizer = train_ops.AdamW(
             [{'params': self.AudEnc.parameters()}, {'params': self.Predictor.parameters()},
              {'params': self.TextEnc.parameters()}],
             lr=self.config.Train.learning_rate.generator_learning_rate, betas=[0.9, 0.99])
@@ -79,7 +91,64 @@ class TrainWrapper(TrainWrapperBaseClass):
             self.generator_optimizer.load_state_dict(state_dict['generator_optim'])
 
     def __call__(self, bat):
-        raise NotImplementedError("s2g_body_predictor training step (fwd+bwd+AdamW) is not built yet")
+        """One training step (predictor.py:168-280): frozen PQ-VAE codes as targets, AudEnc + PredictorNet forward in
+        train mode, cross-entropy over all tokens, backward, per-module gradient clipping, AdamW — all on HIP kernels
+        (probtalk_amd.training / train_ops).  Optional test hooks in `bat`: '_mask' (B,1,T) and '_keep_scores' (B,N)
+        replace the two random draws of the step."""
+        self.global_step += 1
+        dev = 'cuda'
+        aud = bat['aud_feat'].to(dev).to(torch.float32)
+        poses = bat['poses'].to(dev).to(torch.float32)
+        expression = bat['expression'].to(dev).to(torch.float32)
+        id = bat['speaker'].to(dev)
+        jaw = poses[:, :self.each_dim[0], :]
+        poses = poses[:, self.c_index, :]
+        if self.type == 'fbhe':
+            poses = torch.cat([jaw, poses, expression], dim=1)
+        elif self.type == 'fe':
+            poses = torch.cat([jaw, expression], dim=1)
+        gt_poses = poses.contiguous()
+        bs, n, t = gt_poses.size()
+        epoch = bat['epoch']
+        if '_mask' in bat:
+            mask = bat['_mask'].to(dev).to(torch.float32)
+        elif self.motion_context:
+            select = torch.randint(0, self.random_mask.shape[0], (bs,))
+            mask = self.random_mask[select].clone()
+            mask[:64] = 0
+            mask = mask.to(dev)
+        else:
+            mask = torch.zeros([bs, 1, t], device=dev)
+        input_poses = gt_poses * mask
+        self.VQ.eval()
+        with torch.no_grad():
+            _, qo_gt, _ = self.VQ.encode(gt_poses=gt_poses)
+            state = qo_gt.loss
+        if self.text:
+            raise NotImplementedError("text conditioning (p_text) is off in config/transformer.json and not built")
+        epoch_ratio = min(max(epoch / 99, 0.5), 1)
+        for m in (self.AudEnc, self.Predictor):
+            if next(m.parameters()).device.type != 'cuda':
+                m.cuda()
+            m.train()
+        Pa, Pp = training.tensors_of(self.AudEnc), training.tensors_of(self.Predictor)
+        N = state.shape[1] * state.shape[2]
+        keep_scores = bat['_keep_scores'].to(dev) if '_keep_scores' in bat else torch.rand(bs, N, device=dev)
+        self.generator_optimizer.zero_grad()
+        loss, _ = training.predictor_loss(Pa, Pp, aud, input_poses, mask, id.reshape(-1), state, keep_scores, epoch_ratio,
+                                          p_drop=self.train_dropout, seeds=self._seeds, groups=self.config.Model.groups)
+        loss.backward()
+        max_norm = self.config.Train.max_gradient_norm
+        pa, pp = list(self.AudEnc.parameters()), list(self.Predictor.parameters())
+        grad_ae, coef_ae = train_ops.clip_grad_norm(pa, max_norm)
+        grad_p, coef_p = train_ops.clip_grad_norm(pp, max_norm)
+        coefs = {p: coef_ae for p in pa}
+        coefs.update({p: coef_p for p in pp})
+        self.generator_optimizer.step(coefs)
+        self.AudEnc.invalidate()          # the packed inference weights are stale now
+        self.Predictor.invalidate()
+        loss_dict = {'logits': loss, 'loss': loss.item(), 'grad_ae': grad_ae.item(), 'grad_p': grad_p.item()}
+        return None, loss_dict
 
     def _eval(self):
         self.AudEnc.eval(), self.TextEnc.eval(), self.Predictor.eval(), self.VQ.eval()
