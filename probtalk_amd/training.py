@@ -41,6 +41,8 @@ def cond_encoder_train(P, x_rows, B, Tn, p_drop, seeds, prefix=""):
 
 
 # ------------------------------------------------------------------------------------------- motion-context encoder
+relu_trace = None      # tests set this to a list to receive each FFN's post-ReLU activations (which side of 0 a unit fell)
+
 GATED_KIND = [2, 1, 3, 1, 3, 1, 3, 1, 1, 1]     # enc.0 .. enc.9: k7 | k3 | k4 s2 | ... (predictornet.py:36-49)
 
 
@@ -84,6 +86,8 @@ def decoder_layer_train(P, p, x, mem, silu_ce, label, B, N, Nm, p_drop, seeds):
     x = T.layer_norm(x, P[p + "norm2.weight"], P[p + "norm2.bias"], res=t)
 
     hdn = T.conv(x, P[p + "linear1.weight"], P[p + "linear1.bias"], 0, 1, R, slope=0.0)
+    if relu_trace is not None:
+        relu_trace.append(hdn.detach())
     hdn = T.dropout(hdn, p_drop, seeds)
     t = T.conv(hdn, P[p + "linear2.weight"], P[p + "linear2.bias"], 0, 1, R)
     t = T.dropout(_style(P, p + "style_gourp_3.", t, silu_ce, label, N), p_drop, seeds)

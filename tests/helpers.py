@@ -42,3 +42,21 @@ def ref_state_dict(module, seed=0):
 def rel_err(a, b):
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+# gradients stored in tests/golden/predictor_train_b2_t88.npz as grad_<i> (tools/make_golden_train.py)
+TRAIN_GRAD_KEYS = [
+    ("AudEnc", "feature_map.0.weight"), ("AudEnc", "feature_map.1.weight"), ("AudEnc", "_down_2.conv.weight"),
+    ("AudEnc", "_down_3.residual_layer.bias"), ("AudEnc", "_down_3.norm.bias"),
+    ("Predictor", "motion_embedding.bias"), ("Predictor", "enc.0.vert_stack.weight"), ("Predictor", "enc.2.conv.weight"),
+    ("Predictor", "enc.9.res.weight"), ("Predictor", "decoder.tok_emb.weight"), ("Predictor", "decoder.class_embed.weight"),
+    ("Predictor", "decoder.condi_emb.bias"),
+    ("Predictor", "decoder.transformer_decoder.layers.0.self_attn.in_proj_bias"),
+    ("Predictor", "decoder.transformer_decoder.layers.0.style_gourp_1.emb_layers_2.1.bias"),
+    ("Predictor", "decoder.transformer_decoder.layers.0.style_gourp_1.norm_2.weight"),
+    ("Predictor", "decoder.transformer_decoder.layers.2.multihead_attn.in_proj_bias"),
+    ("Predictor", "decoder.transformer_decoder.layers.3.linear1.bias"),
+    ("Predictor", "decoder.transformer_decoder.layers.5.norm3.weight"),
+    ("Predictor", "decoder.transformer_decoder.layers.5.style_gourp_3.out_layers_2.2.bias"),
+    ("Predictor", "decoder.output_conv.2.bias"),
+]

@@ -1,16 +1,13 @@
 """CPU: the train-step oracle (oracle/probtalk_oracle_train.py) against the fixture produced by the imported reference
 (tools/make_golden_train.py): loss, logits, per-module gradient norms, a selection of gradients, BatchNorm running mean."""
 import os
-import sys
 
 import numpy as np
 import torch
 
 from oracle import probtalk_oracle_train as OT
 from probtalk_amd.weights import make_input
-from tests.helpers import GOLDEN, ref_state_dict, rel_err
-
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+from tests.helpers import GOLDEN, TRAIN_GRAD_KEYS, ref_state_dict, rel_err
 
 
 def train_case():
@@ -26,8 +23,7 @@ def train_case():
 
 
 def grad_keys():
-    from make_golden_train import GRAD_KEYS
-    return GRAD_KEYS
+    return TRAIN_GRAD_KEYS
 
 
 def test_train_oracle_matches_reference_fixture():
