@@ -61,8 +61,53 @@ def cpu_baseline(B=2, T=300, runs=3):
                       f"fp32, median of {runs} runs after 1 warm-up ({med:.2f} s/run)"}
 
 
+def train_bench(a, rank, world, dev):
+    """BASELINE.json configs[4]: predictor training step (frozen PQ-VAE tokenizer, AudEnc + PredictorNet forward and
+    backward, gradient all-reduce over RCCL when N > 1, per-module clipping, AdamW), `--batch` clips of 180 frames
+    (config Data.pose.generate_length) per GPU per step.  Secondary workload: the default run stays the metric's."""
+    import torch.distributed as dist
+    from probtalk_amd.synthetic import build_pipeline
+    pred, _ = build_pipeline(seed=0)
+    B, T = a.batch, 180
+    g = torch.Generator(device=dev).manual_seed(99 + rank)
+    bat = {"aud_feat": torch.randn(B, 768, T, device=dev, generator=g),
+           "poses": 0.3 * torch.randn(B, 330, T, device=dev, generator=g),
+           "expression": 0.3 * torch.randn(B, 100, T, device=dev, generator=g),
+           "speaker": torch.randint(0, 4, (B,), device=dev, generator=g), "epoch": 50}
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        pred(bat)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        _, ld = pred(bat)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert ld["loss"] == ld["loss"], "non-finite loss"
+    res = {"metric": "predictor training frames/sec (fwd+bwd+all-reduce+clip+AdamW)", "value": world * B * T * a.steps / dt,
+           "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "configs[4]: s2g_body_predictor TrainWrapper.__call__ (frozen PQ-VAE encode, AudEnc + "
+                                  "PredictorNet train forward with dropout 0.1, cross-entropy, backward, clip, AdamW)",
+                      "clips_per_step_per_gpu": B, "frames_per_clip": T, "last_loss": ld["loss"],
+                      "parallelism": f"dp{world}: clips sharded over ranks, bucketed gradient all-reduce over RCCL"}}
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=("infer", "train"), default="infer",
+                    help="infer (default): the metric's full pipeline; train: configs[4] predictor training step")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -83,6 +128,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+    if a.workload == "train":
+        train_bench(a, rank, world, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     from probtalk_amd import _lib
     from probtalk_amd.dist import OutputGatherer
     from probtalk_amd.synthetic import build_pipeline, holistic_step

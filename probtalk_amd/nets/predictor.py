@@ -140,6 +140,14 @@ class TrainWrapper(TrainWrapperBaseClass):
         loss.backward()
         max_norm = self.config.Train.max_gradient_norm
         pa, pp = list(self.AudEnc.parameters()), list(self.Predictor.parameters())
+        if torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            # one process per GPU in place of nn.DataParallel (to_parallel): mean gradient over ranks, rank 0's BN buffers
+            if self.__dict__.get('_reducer') is None:
+                from ..dist import GradientReducer
+                self._reducer = GradientReducer(pa + pp, list(self.AudEnc.buffers()) + list(self.Predictor.buffers()))
+            self._reducer.reduce()
+            self._reducer.sync_buffers()
         grad_ae, coef_ae = train_ops.clip_grad_norm(pa, max_norm)
         grad_p, coef_p = train_ops.clip_grad_norm(pp, max_norm)
         coefs = {p: coef_ae for p in pa}

@@ -50,3 +50,40 @@ def _worker(rank, world, port, n_clips):
 def test_shard_gather_world2_even_and_ragged():
     for n in (8, 7):
         mp.spawn(_worker, args=(2, _free_port(), n), nprocs=2, join=True)
+
+
+def _grad_worker(rank, world, port):
+    from probtalk_amd.dist import GradientReducer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(0)
+        shapes = [(300, 7), (5,), (1000,), (64, 64), (3,), (17, 2)]
+        params = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+        frozen = torch.nn.Parameter(torch.randn(4), requires_grad=False)
+        grads = [[torch.randn(s, generator=g) for s in shapes] for _ in range(world)]      # same on every rank
+        for p, gr in zip(params, grads[rank]):
+            p.grad = gr.clone()
+        params[4].grad = None                                   # unused parameter: no gradient on any rank
+        bn = torch.full((8,), float(rank + 1))
+        red = GradientReducer(params + [frozen], [bn, torch.tensor(3)], bucket_bytes=4096)
+        assert len(red.buckets) >= 2 and sum(len(b) for b in red.buckets) == len(params)
+        for _ in range(2):                                      # twice: flat buffers are reused
+            for p, gr in zip(params, grads[rank]):
+                if p.grad is not None:
+                    p.grad.copy_(gr)
+            red.reduce()
+            for i, p in enumerate(params):
+                if i == 4:
+                    assert p.grad is None
+                else:
+                    want = sum(grads[r][i] for r in range(world)) / world
+                    assert torch.allclose(p.grad, want, atol=1e-6)
+        red.sync_buffers()
+        assert torch.equal(bn, torch.full((8,), 1.0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_reducer_world2():
+    mp.spawn(_grad_worker, args=(2, _free_port()), nprocs=2, join=True)
