@@ -8,6 +8,8 @@
 // Reference lines: predictor.py:168-280 (train step), PTransformer.py:443-504 (train forward), 28-165 (style block),
 // vqvae_modules.py:107-200 (ConvNormRelu with batch statistics), torch.optim.AdamW, torch.nn.utils.clip_grad_norm_.
 #include <cmath>
+#include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "pt_common.h"
@@ -462,9 +464,268 @@ __global__ __launch_bounds__(256) void attn_fwd_train_kernel(const float* __rest
     o += expf(sc[j] - mx) / l * attn_keep(seed, mbase + j, thr, ks) * V[(size_t)(b * Nk + j) * ldv + h * 64 + lane];
   O[(size_t)(b * Nq + i) * ldo + h * 64 + lane] = o;
 }
+// ---------------------------------------------------------------------------
+// Tiled attention for training (fp32, head dim 64): one 512-thread workgroup per (clip, head) keeps Q, K, V (and dO) of
+// that head and the Nq x Nk score / probability matrices in LDS; every contraction is a register-tiled 4x4 FMA GEMM
+// whose operands are read from LDS as float4, in their natural row-major layout (no transposes):
+//   "kc"  C[m][n] = sum_k A[m][k] B[n][k]   (k contiguous in both: S = Q K^T, dPd = dO V^T)
+//   "km"  C[m][n] = sum_k A[k][m] B[k][n]   (k-major in both:      dV = Pd^T dO, dK = dS^T Q)
+//   "mix" C[m][n] = sum_k A[m][k] B[k][n]   (O = Pd V, dQ = dS K)
+// fp32 MFMA has the same peak as the fp32 vector unit on gfx950 (157 TFLOP/s), so the vector FMAs cost nothing here and
+// keep the summation free of layout shuffles.  LDS need at Nq = Nk = 88 (the predictor's 22 x 4 tokens): 158 KB of the
+// 160 KB, one workgroup per CU.  Shapes that do not fit fall back to the one-wave-per-row kernels above.
+// The dropout mask index is the same ((b*H+h)*Nq+i)*Nk+j as in those kernels.
+// ---------------------------------------------------------------------------
+constexpr int AT = 512;
+__host__ __device__ inline int at_ru4(int n) { return (n + 3) & ~3; }
+__host__ __device__ inline int at_pitch(int n) { int p = at_ru4(n); return (p & 7) == 4 ? p : p + 4; }   // odd multiple of 4
+
+__device__ __forceinline__ void at_load_rows(float* dst, int pitch, const float* __restrict__ src, int ld, int n, int npad) {
+  for (int e = threadIdx.x; e < npad * 16; e += AT) {
+    const int r = e >> 4, c = (e & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < n) v = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c);
+    *reinterpret_cast<float4*>(dst + r * pitch + c) = v;
+  }
+}
+// kc tile: rows m = mi + a*TM (interleaved: consecutive lanes hit consecutive LDS rows), n = n0 + c, K = 64
+__device__ __forceinline__ void at_kc(const float* A, int lda, const float* B, int ldb, int mi, int TM, int n0, float (&acc)[4][4]) {
+#pragma unroll 4
+  for (int k = 0; k < 64; k += 4) {
+    float4 a[4], b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const float4*>(A + (mi + r * TM) * lda + k);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const float4*>(B + (n0 + c) * ldb + k);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        acc[r][c] += a[r].x * b[c].x + a[r].y * b[c].y + a[r].z * b[c].z + a[r].w * b[c].w;
+  }
+}
+// km tile: C[m0+r][n0+c] += sum_{k<K} A[k][m0+r] * B[k][n0+c]
+__device__ __forceinline__ void at_km(const float* A, int lda, const float* B, int ldb, int K, int m0, int n0, float (&acc)[4][4]) {
+#pragma unroll 4
+  for (int k = 0; k < K; ++k) {
+    const float4 a = *reinterpret_cast<const float4*>(A + k * lda + m0);
+    const float4 b = *reinterpret_cast<const float4*>(B + k * ldb + n0);
+    const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[r][c] += av[r] * bv[c];
+  }
+}
+// mix tile: C[m0+r][n0+c] += sum_{k<K4} A[m0+r][k] * B[k][n0+c]   (K4 multiple of 4, pads zero)
+__device__ __forceinline__ void at_mix(const float* A, int lda, const float* B, int ldb, int K4, int m0, int n0, float (&acc)[4][4]) {
+#pragma unroll 2
+  for (int k = 0; k < K4; k += 4) {
+    float4 a[4], b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const float4*>(A + (m0 + r) * lda + k);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) b[kk] = *reinterpret_cast<const float4*>(B + (k + kk) * ldb + n0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc[r][0] += a[r].x * b[0].x + a[r].y * b[1].x + a[r].z * b[2].x + a[r].w * b[3].x;
+      acc[r][1] += a[r].x * b[0].y + a[r].y * b[1].y + a[r].z * b[2].y + a[r].w * b[3].y;
+      acc[r][2] += a[r].x * b[0].z + a[r].y * b[1].z + a[r].z * b[2].z + a[r].w * b[3].z;
+      acc[r][3] += a[r].x * b[0].w + a[r].y * b[1].w + a[r].z * b[2].w + a[r].w * b[3].w;
+    }
+  }
+}
+__device__ __forceinline__ void at_store_rows(float* __restrict__ dst, int ld, int m0, int n0, int nrows, const float (&acc)[4][4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (m0 + r < nrows)
+      *reinterpret_cast<float4*>(dst + (size_t)(m0 + r) * ld + n0) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+}
+
+__global__ __launch_bounds__(AT) void attn_fwd_tiled_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
+                                                            int ldk, const float* __restrict__ V, int ldv, float* __restrict__ O,
+                                                            int ldo, int Nq, int Nk, int H, float scale, float pdrop,
+                                                            unsigned long long seed) {
+  extern __shared__ __attribute__((aligned(16))) float at_sm[];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int NQ4 = at_ru4(Nq), NK4 = at_ru4(Nk), pp = at_pitch(Nk);
+  float* Qs = at_sm;                  // [NQ4][68]
+  float* Ks = Qs + NQ4 * 68;          // [NK4][64]
+  float* Vs = Ks + NK4 * 64;          // [NK4][64]
+  float* Ps = Vs + NK4 * 64;          // [NQ4][pp]
+  at_load_rows(Qs, 68, Q + (size_t)b * Nq * ldq + h * 64, ldq, Nq, NQ4);
+  at_load_rows(Ks, 64, K + (size_t)b * Nk * ldk + h * 64, ldk, Nk, NK4);
+  at_load_rows(Vs, 64, V + (size_t)b * Nk * ldv + h * 64, ldv, Nk, NK4);
+  __syncthreads();
+  const int TM = NQ4 / 4, TN = NK4 / 4;
+  for (int t = threadIdx.x; t < TM * TN; t += AT) {
+    const int mi = t % TM, n0 = (t / TM) * 4;
+    float acc[4][4] = {};
+    at_kc(Qs, 68, Ks, 64, mi, TM, n0, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<float4*>(Ps + (mi + r * TM) * pp + n0) =
+          make_float4(acc[r][0] * scale, acc[r][1] * scale, acc[r][2] * scale, acc[r][3] * scale);
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned thr = (unsigned)((double)pdrop * 4294967296.0);
+  const float ks = 1.f / (1.f - pdrop);
+  for (int i = wave; i < NQ4; i += AT / 64) {
+    float* row = Ps + i * pp;
+    if (i >= Nq) {
+      for (int j = lane; j < NK4; j += 64) row[j] = 0.f;
+      continue;
+    }
+    float mx = -INFINITY;
+    for (int j = lane; j < Nk; j += 64) mx = fmaxf(mx, row[j]);
+    mx = wmax(mx);
+    float l = 0.f;
+    for (int j = lane; j < Nk; j += 64) l += expf(row[j] - mx);
+    l = wsum(l);
+    const size_t mbase = ((size_t)(b * H + h) * Nq + i) * Nk;
+    for (int j = lane; j < NK4; j += 64) {
+      float pj = 0.f;
+      if (j < Nk) {
+        pj = expf(row[j] - mx) / l;
+        if (pdrop > 0.f) pj *= attn_keep(seed, mbase + j, thr, ks);
+      }
+      row[j] = pj;
+    }
+  }
+  __syncthreads();
+  float* Ob = O + (size_t)b * Nq * ldo + h * 64;
+  for (int t = threadIdx.x; t < TM * 16; t += AT) {
+    const int n0 = (t & 15) * 4, m0 = (t >> 4) * 4;
+    float acc[4][4] = {};
+    at_mix(Ps, pp, Vs, 64, NK4, m0, n0, acc);
+    at_store_rows(Ob, ldo, m0, n0, Nq, acc);
+  }
+}
+
+template <int JMAX>
+__global__ __launch_bounds__(AT) void attn_bwd_tiled_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
+                                                            int ldk, const float* __restrict__ V, int ldv,
+                                                            const float* __restrict__ dO, int ldo, float* __restrict__ dQ,
+                                                            int lddq, float* __restrict__ dK, int lddk, float* __restrict__ dV,
+                                                            int lddv, int Nq, int Nk, int H, float scale, float pdrop,
+                                                            unsigned long long seed) {
+  extern __shared__ __attribute__((aligned(16))) float at_sm[];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int NQ4 = at_ru4(Nq), NK4 = at_ru4(Nk), pp = at_pitch(Nk);
+  float* Qs = at_sm;                  // [NQ4][68]
+  float* Gs = Qs + NQ4 * 68;          // dO [NQ4][68]
+  float* Ks = Gs + NQ4 * 68;          // [NK4][64]
+  float* Vs = Ks + NK4 * 64;          // [NK4][64]
+  float* Ps = Vs + NK4 * 64;          // S, then Pd = P * keep        [NQ4][pp]
+  float* Ds = Ps + NQ4 * pp;          // dPd, then dS                 [NQ4][pp]
+  at_load_rows(Qs, 68, Q + (size_t)b * Nq * ldq + h * 64, ldq, Nq, NQ4);
+  at_load_rows(Gs, 68, dO + (size_t)b * Nq * ldo + h * 64, ldo, Nq, NQ4);
+  at_load_rows(Ks, 64, K + (size_t)b * Nk * ldk + h * 64, ldk, Nk, NK4);
+  at_load_rows(Vs, 64, V + (size_t)b * Nk * ldv + h * 64, ldv, Nk, NK4);
+  __syncthreads();
+  const int TM = NQ4 / 4, TN = NK4 / 4;
+  for (int t = threadIdx.x; t < TM * TN; t += AT) {
+    const int mi = t % TM, n0 = (t / TM) * 4;
+    float acc[4][4] = {}, acd[4][4] = {};
+    at_kc(Qs, 68, Ks, 64, mi, TM, n0, acc);
+    at_kc(Gs, 68, Vs, 64, mi, TM, n0, acd);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      *reinterpret_cast<float4*>(Ps + (mi + r * TM) * pp + n0) =
+          make_float4(acc[r][0] * scale, acc[r][1] * scale, acc[r][2] * scale, acc[r][3] * scale);
+      *reinterpret_cast<float4*>(Ds + (mi + r * TM) * pp + n0) = make_float4(acd[r][0], acd[r][1], acd[r][2], acd[r][3]);
+    }
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned thr = (unsigned)((double)pdrop * 4294967296.0);
+  const float ks = 1.f / (1.f - pdrop);
+  for (int i = wave; i < NQ4; i += AT / 64) {
+    float* prow = Ps + i * pp;
+    float* drow = Ds + i * pp;
+    if (i >= Nq) {
+      for (int j = lane; j < NK4; j += 64) { prow[j] = 0.f; drow[j] = 0.f; }
+      continue;
+    }
+    float sv[JMAX], mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < JMAX; ++u) {
+      const int j = lane + 64 * u;
+      sv[u] = j < Nk ? prow[j] : -INFINITY;
+      mx = fmaxf(mx, sv[u]);
+    }
+    mx = wmax(mx);
+    float l = 0.f;
+#pragma unroll
+    for (int u = 0; u < JMAX; ++u) {
+      sv[u] = (lane + 64 * u) < Nk ? expf(sv[u] - mx) : 0.f;
+      l += sv[u];
+    }
+    l = wsum(l);
+    const size_t mbase = ((size_t)(b * H + h) * Nq + i) * Nk;
+    float kp[JMAX], dp[JMAX], dl = 0.f;
+#pragma unroll
+    for (int u = 0; u < JMAX; ++u) {
+      const int j = lane + 64 * u;
+      sv[u] = sv[u] / l;                                        // P
+      kp[u] = (pdrop > 0.f && j < Nk) ? attn_keep(seed, mbase + j, thr, ks) : 1.f;
+      dp[u] = j < Nk ? drow[j] * kp[u] : 0.f;                   // dP = dPd * keep
+      dl += sv[u] * dp[u];
+    }
+    dl = wsum(dl);
+#pragma unroll
+    for (int u = 0; u < JMAX; ++u) {
+      const int j = lane + 64 * u;
+      if (j < NK4) {
+        prow[j] = j < Nk ? sv[u] * kp[u] : 0.f;                 // Pd
+        drow[j] = j < Nk ? sv[u] * (dp[u] - dl) * scale : 0.f;  // dS (scale folded)
+      }
+    }
+  }
+  __syncthreads();
+  float* dKb = dK + (size_t)b * Nk * lddk + h * 64;
+  float* dVb = dV + (size_t)b * Nk * lddv + h * 64;
+  float* dQb = dQ + (size_t)b * Nq * lddq + h * 64;
+  const int nkv = TN * 16, nq = TM * 16;
+  for (int t = threadIdx.x; t < nkv + nq; t += AT) {
+    if (t < nkv) {
+      const int n0 = (t & 15) * 4, m0 = (t >> 4) * 4;
+      float av[4][4] = {}, ak[4][4] = {};
+      at_km(Ps, pp, Gs, 68, Nq, m0, n0, av);                    // dV = Pd^T dO
+      at_km(Ds, pp, Qs, 68, Nq, m0, n0, ak);                    // dK = dS^T Q
+      at_store_rows(dVb, lddv, m0, n0, Nk, av);
+      at_store_rows(dKb, lddk, m0, n0, Nk, ak);
+    } else {
+      const int u = t - nkv, n0 = (u & 15) * 4, m0 = (u >> 4) * 4;
+      float aq[4][4] = {};
+      at_mix(Ds, pp, Ks, 64, NK4, m0, n0, aq);                  // dQ = dS K
+      at_store_rows(dQb, lddq, m0, n0, Nq, aq);
+    }
+  }
+}
+
+static size_t at_lds_bytes(int Nq, int Nk, bool bwd) {
+  const size_t q = (size_t)at_ru4(Nq) * 68, k = (size_t)at_ru4(Nk) * 64, p = (size_t)at_ru4(Nq) * at_pitch(Nk);
+  return 4 * (bwd ? 2 * q + 2 * k + 2 * p : q + 2 * k + p);
+}
+static bool at_aligned(const void* p, int ld) { return ((uintptr_t)p & 15) == 0 && (ld & 3) == 0; }
+
 int launch_attention_train_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,
                                int Nq, int Nk, int H, float pdrop, unsigned long long seed, hipStream_t s) {
   PT_CHECK(Q && K && V && O && B > 0 && Nq > 0 && Nk > 0 && H > 0 && pdrop >= 0.f && pdrop < 1.f, "attention_train_fwd: bad argument");
+  if (at_lds_bytes(Nq, Nk, false) <= 160 * 1024 && at_aligned(Q, ldq) && at_aligned(K, ldk) && at_aligned(V, ldv) &&
+      at_aligned(O, ldo) && !getenv("PT_ATTN_TRAIN_ROWWISE")) {
+    static bool attr = false;
+    if (!attr) {
+      PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 160 * 1024));
+      attr = true;
+    }
+    PT_LAUNCH(attn_fwd_tiled_kernel, dim3(B * H), dim3(AT), at_lds_bytes(Nq, Nk, false), s, Q, ldq, K, ldk, V, ldv, O, ldo, Nq,
+              Nk, H, 0.125f, pdrop, seed);
+    return 0;
+  }
   PT_CHECK(Nk <= 4096, "attention_train_fwd: %d keys exceed the per-wave score buffer", Nk);
   PT_LAUNCH(attn_fwd_train_kernel, dim3((B * H * Nq + 3) / 4), dim3(256), (size_t)4 * Nk * sizeof(float), s, Q, ldq, K, ldk, V,
             ldv, O, ldo, B, Nq, Nk, H, 0.125f, pdrop, seed);
@@ -474,6 +735,19 @@ int launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const
                          float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, float* lse, float* delta, int B,
                          int Nq, int Nk, int H, float pdrop, unsigned long long seed, hipStream_t s) {
   PT_CHECK(Q && K && V && dO && dQ && dK && dV && lse && delta && B > 0 && Nq > 0 && Nk > 0 && H > 0, "attention_bwd: bad argument");
+  if (at_lds_bytes(Nq, Nk, true) <= 160 * 1024 && Nk <= 128 && at_aligned(Q, ldq) && at_aligned(K, ldk) && at_aligned(V, ldv) &&
+      at_aligned(dO, ldo) && at_aligned(dQ, lddq) && at_aligned(dK, lddk) && at_aligned(dV, lddv) &&
+      !getenv("PT_ATTN_TRAIN_ROWWISE")) {
+    static bool attr = false;
+    if (!attr) {
+      PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_tiled_kernel<2>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr = true;
+    }
+    PT_LAUNCH(attn_bwd_tiled_kernel<2>, dim3(B * H), dim3(AT), at_lds_bytes(Nq, Nk, true), s, Q, ldq, K, ldk, V, ldv, dO, ldo, dQ,
+              lddq, dK, lddk, dV, lddv, Nq, Nk, H, 0.125f, pdrop, seed);
+    return 0;
+  }
   PT_CHECK(Nk <= 2048, "attention_bwd: %d keys exceed the per-wave score buffer", Nk);
   const size_t smem = (size_t)4 * 2 * Nk * sizeof(float);
   PT_LAUNCH(attn_bwd_q_kernel, dim3((B * H * Nq + 3) / 4), dim3(256), smem, s, Q, ldq, K, ldk, V, ldv, dO, ldo, dQ, lddq, lse,

@@ -191,6 +191,34 @@ def test_attention_dropout_replay_and_scale():
     assert abs(lhs - rhs) < 1e-4 * abs(lhs)
 
 
+@pytest.mark.parametrize("B,Nq,Nk,p", [(3, 88, 88, 0.1), (2, 88, 22, 0.1), (1, 7, 3, 0.25), (2, 100, 100, 0.0), (1, 130, 40, 0.1)])
+def test_attention_tiled_matches_rowwise(B, Nq, Nk, p):
+    """The LDS-tiled (clip, head) kernels and the one-wave-per-row fallback share the dropout mask indexing: same
+    outputs and gradients for the same seed.  (100x100 and 130x40 exceed the LDS budget / key bound: both runs take the
+    fallback there, which checks the dispatch.)"""
+    g = torch.Generator().manual_seed(Nq + Nk)
+    q, kv = torch.randn(B * Nq, 512, generator=g).cuda(), torch.randn(B * Nk, 1024, generator=g).cuda()
+    do = torch.randn(B * Nq, 512, generator=g).cuda()
+
+    class Fixed:
+        def next(self):
+            return 99
+
+    res = []
+    for rowwise in (False, True):
+        if rowwise:
+            os.environ["PT_ATTN_TRAIN_ROWWISE"] = "1"
+        try:
+            qd, kvd = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+            o = T.Attention.apply(qd, kvd, 0, 0, 512, B, Nq, Nk, p, 99) if p > 0 else T.attention_cross(qd, kvd, B, Nq, Nk)
+            o.backward(do)
+            res.append((o.detach(), qd.grad, kvd.grad))
+        finally:
+            os.environ.pop("PT_ATTN_TRAIN_ROWWISE", None)
+    for a, b_ in zip(*res):
+        assert rel_err(a.cpu(), b_.cpu()) < 1e-5
+
+
 def test_cross_entropy():
     g = torch.Generator().manual_seed(2)
     logits = 3 * torch.randn(352, 128, generator=g)
