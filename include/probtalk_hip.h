@@ -201,6 +201,29 @@ int pt_train_clip_coef(const float* sumsq, float max_norm, float* coef, float* n
 int pt_train_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* gscale, float lr, float beta1,
                    float beta2, float eps, float wd, int step, void* stream);
 int pt_train_add(const float* a, const float* b, float* out, size_t n, void* stream);
+/* ProductQuantization.forward train branch (vqvae_modules.py:495-534): EMA cluster sizes / code sums from the assigned
+ * latent rows, Laplace smoothing, dead-code re-seeding from the first K latent rows, new codebooks.  z rows [rows, ldz]
+ * (G*D used columns), idx int64 [rows, G]; counts [G,K] and dw [G,K,D] are scratch; cs_hidden [G,K], dw_hidden [G,K,D],
+ * emb [G,K,D] are the module's buffers (ema_cluster_size.i.hidden, ema_dw.i.hidden, embeddings_i) stacked over i;
+ * counter = the EMA modules' call count including this call.  rows >= K required. */
+int pt_train_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw,
+                    float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, void* stream);
+/* vq_teacher.TrainWrapper.get_loss (vq_teacher.py:184-232) on channels-last rows [B*T, ld]: smooth-L1(beta) mean per
+ * column range bounds[p]..bounds[p+1] (host arrays, nparts <= 4), velocity L1 mean over the first vel_cols columns;
+ * sums (device, nparts+2 floats) = part means | velocity mean | sum_p weights[p]*part_p + velocity; dpred = gradient of
+ * that total. */
+int pt_train_vq_losses(const float* pred, int ldp, const float* gt, int ldg, int B, int T, int nparts, const int* bounds,
+                       const float* weights, int vel_cols, float beta, float* sums, float* dpred, int lddp, void* stream);
+/* refiner.TrainWrapper.get_loss (refiner.py:313-391): per part sum |pred - gt| * nmask[row] / (t_nmask * cols) with
+ * nmask = 1 - mask per frame row and t_nmask = sum(nmask); velocity L1 mean (unmasked) over the first vel_cols columns;
+ * sums / dpred as in pt_train_vq_losses. */
+int pt_train_masked_l1_losses(const float* pred, int ldp, const float* gt, int ldg, const float* nmask, float t_nmask, int B, int T,
+                              int nparts, const int* bounds, const float* weights, int vel_cols, float* sums, float* dpred,
+                              int lddp, void* stream);
+/* commitment loss (vqvae_modules.py:537-541): *out += sum (a-b)^2 ; dz = dq + (*g) * coef * (z - q) (dq, g may be NULL) */
+int pt_train_sqdiff(const float* a, const float* b, size_t n, float* out, void* stream);
+int pt_train_commit_bwd(const float* dq, const float* z, const float* q, const float* g, float coef, size_t n, float* dz,
+                        void* stream);
 /* debug aid: device buffer of 256*64 uint64 that the following pt_gemm_bf16* calls fill with per-workgroup phase
  * timestamps (tools/gemm_stamps.py); NULL switches it off */
 int pt_debug_set_stamps(void* buf);

@@ -87,3 +87,104 @@ def adamw_step(p, g, m, v, step, lr, betas=(0.9, 0.99), eps=1e-8, wd=1e-2):
     bc1, bc2 = 1 - betas[0] ** step, 1 - betas[1] ** step
     p = p - (lr / bc1) * m / (v.sqrt() / math.sqrt(bc2) + eps)
     return p, m, v
+
+
+# ------------------------------------------------------------------------------------------------ PQ-VAE train step
+def pq_train(sd, p, z, groups, commitment_cost=0.25, decay=0.99, eps=1e-5, counter=1):
+    """ProductQuantization.forward, training branch, share_code False (vqvae_modules.py:470-487,495-544).
+    -> (quantized with straight-through gradient (B,C,W), commitment loss, indices (BW, G), updated buffers)."""
+    B, C, W = z.shape
+    D = C // groups
+    x = z.permute(0, 2, 1)
+    flat = x.reshape(-1, groups, D)
+    K = sd[f"{p}embeddings_0"].shape[0]
+    assert flat.shape[0] >= K, "the noisy re-tiling of short batches (571-580) is not restated"
+    idx, q, new = [], [], {}
+    for i in range(groups):
+        emb = sd[f"{p}embeddings_{i}"]
+        ind = torch.argmin(O.code_distances(flat[:, i].detach(), emb), dim=1)
+        idx.append(ind)
+        q.append(F.embedding(ind, emb).reshape(B, W, D))
+    quantized = torch.cat(q, dim=-1)
+    with torch.no_grad():
+        corr = 1 - decay ** counter
+        for i in range(groups):
+            enc = F.one_hot(idx[i], K).to(flat.dtype)
+            cs_h = sd[f"{p}ema_cluster_size.{i}.hidden"].clone()
+            cs_h.sub_((cs_h - enc.sum(0)) * (1 - decay))
+            cs = cs_h / corr
+            n = cs.sum()
+            cs = (cs + eps) / (n + K * eps) * n
+            dw_h = sd[f"{p}ema_dw.{i}.hidden"].clone()
+            dw_h.sub_((dw_h - enc.t() @ flat[:, i].detach()) * (1 - decay))
+            normalised = (dw_h / corr) / cs.reshape(-1, 1)
+            code_rand = flat[:K, i].detach()
+            usage = (cs.view(K, 1) >= 1.0).float()
+            new[f"{p}ema_dw.{i}.hidden"] = usage * dw_h + (1 - usage) * code_rand
+            new[f"{p}ema_cluster_size.{i}.hidden"] = cs_h * usage.view(-1) + (1 - usage).view(-1)
+            new[f"{p}embeddings_{i}"] = usage * normalised + (1 - usage) * code_rand
+    loss = commitment_cost * F.mse_loss(x, quantized.detach())
+    quantized = x + (quantized - x).detach()
+    return quantized.permute(0, 2, 1), loss, torch.stack(idx, dim=1), new
+
+
+def vq_losses(pred, gt, dim_list=(0, 6, 6, 96, 276), exp_dim=100):
+    """vq_teacher.get_loss, type 'fbhe' (vq_teacher.py:191-203,222-229), pred/gt (B,T,C) -> (rec + velocity, parts)."""
+    d = dim_list
+    sl1 = lambda a, b: F.smooth_l1_loss(a, b, beta=0.01)
+    face = sl1(pred[..., :d[1]], gt[..., :d[1]])
+    body = sl1(pred[..., d[1]:d[3]], gt[..., d[1]:d[3]])
+    hand = sl1(pred[..., d[3]:d[4]], gt[..., d[3]:d[4]])
+    exp = sl1(pred[..., d[4]:], gt[..., d[4]:])
+    weight = 0.4
+    rec = (face + exp) * (0.5 - weight) + (body + hand) * weight
+    v_pr = pred[:, 1:, :-exp_dim] - pred[:, :-1, :-exp_dim]
+    v_gt = gt[:, 1:, :-exp_dim] - gt[:, :-1, :-exp_dim]
+    vel = torch.mean(torch.abs(v_pr - v_gt))
+    return rec + vel, {"face_loss": face, "body_loss": body, "hand_loss": hand, "exp_loss": exp, "velocity_loss": vel}
+
+
+def vq_train_grads(sd, x, groups=4, counter=1):
+    """One vq_teacher step up to the gradients (vq_teacher.py:167-177): -> (loss, parts, grads, new buffers, pred)."""
+    leaf = {k: (v.detach().clone().requires_grad_(True)
+                if v.dtype == torch.float32 and "running" not in k and "embeddings_" not in k and "hidden" not in k else v)
+            for k, v in sd.items()}
+    running = {}
+    with bn_train_mode(running):
+        z = O.encoder_sc(leaf, "encoder.", x)
+        e, e_q_loss, idx, new = pq_train(leaf, "vq_layer.", z, groups, counter=counter)
+        pred = O.decoder_sc(leaf, "decoder.", e)
+    rec, parts = vq_losses(pred.transpose(1, 2), x.transpose(1, 2))
+    loss = rec + e_q_loss
+    loss.backward()
+    parts["e_q_loss"] = e_q_loss.detach()
+    grads = {k: v.grad for k, v in leaf.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None}
+    new.update(running)
+    return loss.detach(), parts, grads, new, pred.detach(), idx
+
+
+# ------------------------------------------------------------------------------------------------ refiner train step
+def refiner_losses(pred, gt, mask, dim_list=(0, 6, 6, 96, 276), each_dim=(6, 90, 180, 100)):
+    """refiner.get_loss, type 'fbhe' (refiner.py:321-349,371-391): pred/gt (B,C,T), mask (B,1,T)."""
+    d = dim_list
+    nmask = 1 - mask
+    t_nmask = nmask.sum()
+    part = lambda lo, hi, n: torch.abs(pred[:, lo:hi] * nmask - gt[:, lo:hi] * nmask).sum() / (t_nmask * n)
+    face, body = part(0, d[1], each_dim[0]), part(d[1], d[3], each_dim[1])
+    hand, exp = part(d[3], d[4], each_dim[2]), part(d[4], pred.shape[1], each_dim[3])
+    rec = (face + body + hand + exp) / 4
+    v_pr = pred[:, :-each_dim[3], 1:] - pred[:, :-each_dim[3], :-1]
+    v_gt = gt[:, :-each_dim[3], 1:] - gt[:, :-each_dim[3], :-1]
+    vel = torch.mean(torch.abs(v_pr - v_gt))
+    return rec + vel, {"face_loss": face, "body_loss": body, "hand_loss": hand, "exp_loss": exp, "rec_loss": rec,
+                       "velocity_loss": vel}
+
+
+def refiner_train_grads(sd, aud, input_poses, gt_poses, mask, label):
+    """refiner.py:296-300 with dropout off: -> (loss, parts, {key: grad}, pred)."""
+    leaf = {k: (v.detach().clone().requires_grad_(True) if v.dtype == torch.float32 else v) for k, v in sd.items()}
+    pred = O.rtransformer(leaf, input_poses, aud, mask, label)
+    loss, parts = refiner_losses(pred, gt_poses, mask)
+    loss.backward()
+    grads = {k: v.grad for k, v in leaf.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None}
+    return loss.detach(), parts, grads, pred.detach()

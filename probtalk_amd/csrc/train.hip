@@ -7,6 +7,7 @@
 //   dX of the k4 s2 transposed conv = the k4 s2 conv form.
 // Reference lines: predictor.py:168-280 (train step), PTransformer.py:443-504 (train forward), 28-165 (style block),
 // vqvae_modules.py:107-200 (ConvNormRelu with batch statistics), torch.optim.AdamW, torch.nn.utils.clip_grad_norm_.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -1055,6 +1056,208 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
 int launch_add(const float* a, const float* b, float* out, size_t n, hipStream_t s) {
   PT_CHECK(a && b && out && n > 0, "add: bad argument");
   PT_LAUNCH(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, a, b, out, n);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// PQ-VAE training pieces (vq_teacher.py:135-232, vqvae_modules.py:495-544).
+// ---------------------------------------------------------------------------
+// EMA codebook statistics: counts[g][k] = #rows assigned, dw[g][k][:] = sum of their latent chunks (the reference's
+// one_hot^T . flat_x, vqvae_modules.py:515-520).  One wave per (row, group).
+__global__ __launch_bounds__(256) void pq_ema_accum_kernel(const float* __restrict__ z, int ldz, const int64_t* __restrict__ idx,
+                                                           int rows, int G, int D, int K, float* __restrict__ counts,
+                                                           float* __restrict__ dw) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (size_t w = (size_t)blockIdx.x * 4 + wave; w < (size_t)rows * G; w += (size_t)gridDim.x * 4) {
+    const int row = (int)(w / G), g = (int)(w % G);
+    const int64_t k = idx[(size_t)row * G + g];
+    if (k < 0 || k >= K) continue;
+    float* dst = dw + ((size_t)g * K + k) * D;
+    const float* src = z + (size_t)row * ldz + g * D;
+    for (int d = lane; d < D; d += 64) atomicAdd(dst + d, src[d]);
+    if (lane == 0) atomicAdd(counts + (size_t)g * K + k, 1.f);
+  }
+}
+// hidden -= (hidden - value)(1 - decay); average = hidden / (1 - decay^counter); Laplace smoothing of the cluster sizes;
+// codes whose smoothed size < 1 are re-seeded from the first K latent rows (`_tile`, 571-580, rows >= K) and their EMA
+// state reset (529-534).  One workgroup per group, one thread per code.
+__global__ __launch_bounds__(1024) void pq_ema_finish_kernel(const float* __restrict__ counts, const float* __restrict__ dw,
+                                                             const float* __restrict__ z, int ldz, int D, int K,
+                                                             float* __restrict__ cs_hidden, float* __restrict__ dw_hidden,
+                                                             float* __restrict__ emb, float one_minus_decay, float eps,
+                                                             float corr) {
+  __shared__ float red[16];
+  const int g = blockIdx.x, k = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float h = 0.f, avg = 0.f;
+  if (k < K) {
+    h = cs_hidden[(size_t)g * K + k];
+    h -= (h - counts[(size_t)g * K + k]) * one_minus_decay;
+    avg = h / corr;
+  }
+  float part = wsum(avg);
+  if (lane == 0) red[wave] = part;
+  __syncthreads();
+  float n = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) n += red[w];
+  if (k >= K) return;
+  const float sm = (avg + eps) / (n + (float)K * eps) * n;
+  const bool used = sm >= 1.0f;
+  for (int d = 0; d < D; ++d) {
+    const size_t o = ((size_t)g * K + k) * D + d;
+    float hd = dw_hidden[o];
+    hd -= (hd - dw[o]) * one_minus_decay;
+    const float nrm = (hd / corr) / sm;
+    const float rnd = z[(size_t)k * ldz + g * D + d];
+    dw_hidden[o] = used ? hd : rnd;
+    emb[o] = used ? nrm : rnd;
+  }
+  cs_hidden[(size_t)g * K + k] = used ? h : 1.0f;
+}
+int launch_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw,
+                  float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, hipStream_t s) {
+  PT_CHECK(z && idx && counts && dw && cs_hidden && dw_hidden && emb && G > 0 && D > 0 && K > 0, "pq_ema: bad argument");
+  PT_CHECK(K <= 1024, "pq_ema: %d codes per sub-codebook exceed one workgroup", K);
+  PT_CHECK(rows >= K, "pq_ema: %d latent rows < %d codes (the reference's noisy re-tiling of short batches, "
+                      "vqvae_modules.py:573-577, is not built)", rows, K);
+  PT_CHECK(counter >= 1 && decay > 0.f && decay < 1.f, "pq_ema: bad decay / counter");
+  PT_HIP(hipMemsetAsync(counts, 0, sizeof(float) * G * K, s));
+  PT_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)G * K * D, s));
+  const size_t waves = (size_t)rows * G;
+  PT_LAUNCH(pq_ema_accum_kernel, dim3((unsigned)std::min<size_t>((waves + 3) / 4, 65535)), dim3(256), 0, s, z, ldz, idx, rows, G,
+            D, K, counts, dw);
+  const float omd = (float)(1.0 - (double)decay);
+  const float corr = (float)(1.0 - std::pow((double)decay, (double)counter));
+  PT_LAUNCH(pq_ema_finish_kernel, dim3(G), dim3((K + 63) / 64 * 64), 0, s, counts, dw, z, ldz, D, K, cs_hidden, dw_hidden, emb, omd,
+            eps, corr);
+  return 0;
+}
+
+// Reconstruction losses of vq_teacher.get_loss (184-232): per-part smooth-L1 (beta) means over column ranges, weighted,
+// plus the velocity L1 mean over the first vel_cols columns; writes d(total)/d(pred).
+// sums[p] (p < nparts) = part means, sums[nparts] = velocity mean, sums[nparts+1] = weighted total.
+struct VqLossArgs {
+  const float* pred; int ldp;
+  const float* gt; int ldg;
+  float* dpred; int lddp;
+  int B, T, C, nparts, vel_cols;
+  int bounds[5];
+  float w[4];        // weight of each part in the total
+  float inv_cnt[4];  // 1 / (B*T*cols of the part)
+  float inv_vel;     // 1 / (B*(T-1)*vel_cols)
+  float beta;
+  float* sums;
+  const float* nmask;  // per-row weight (1 - mask) of the refiner's masked L1 (refiner.py:337-349), or NULL
+  int l1;              // 0: smooth-L1(beta) (vq_teacher), 1: L1 * nmask (refiner)
+};
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) - (v < 0.f); }
+__global__ __launch_bounds__(256) void vq_loss_kernel(const VqLossArgs a) {
+  __shared__ float red[4][6];
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const size_t total = (size_t)a.B * a.T * a.C;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % a.C);
+    const size_t row = e / a.C;
+    const int t = (int)(row % a.T);
+    const float p = a.pred[row * a.ldp + c], g = a.gt[row * a.ldg + c];
+    const float d = p - g, ad = fabsf(d);
+    int part = 0;
+    while (part + 1 < a.nparts && c >= a.bounds[part + 1]) ++part;
+    float l, grad;
+    if (a.l1) {
+      const float wr = a.nmask ? a.nmask[row] : 1.f;
+      l = ad * wr;
+      grad = sgn(d) * wr * a.inv_cnt[part] * a.w[part];
+    } else {
+      l = ad < a.beta ? 0.5f * d * d / a.beta : ad - 0.5f * a.beta;
+      grad = (ad < a.beta ? d / a.beta : sgn(d)) * a.inv_cnt[part] * a.w[part];
+    }
+    acc[part] += l * a.inv_cnt[part];
+    if (c < a.vel_cols) {
+      if (t + 1 < a.T) {
+        const float vd = (a.pred[(row + 1) * a.ldp + c] - p) - (a.gt[(row + 1) * a.ldg + c] - g);
+        acc[4] += fabsf(vd) * a.inv_vel;
+        grad -= sgn(vd) * a.inv_vel;
+      }
+      if (t > 0) {
+        const float vd = (p - a.pred[(row - 1) * a.ldp + c]) - (g - a.gt[(row - 1) * a.ldg + c]);
+        grad += sgn(vd) * a.inv_vel;
+      }
+    }
+    a.dpred[row * a.lddp + c] = grad;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const float v = wsum(acc[i]);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    const int i = threadIdx.x;
+    if (i < a.nparts) {
+      atomicAdd(a.sums + i, v);
+      atomicAdd(a.sums + a.nparts + 1, v * a.w[i]);
+    } else if (i == 4) {
+      atomicAdd(a.sums + a.nparts, v);
+      atomicAdd(a.sums + a.nparts + 1, v);
+    }
+  }
+}
+int launch_vq_losses(const float* pred, int ldp, const float* gt, int ldg, int B, int T, int nparts, const int* bounds,
+                     const float* weights, int vel_cols, float beta, float* sums, float* dpred, int lddp, hipStream_t s,
+                     const float* nmask, float t_nmask, int l1) {
+  PT_CHECK(pred && gt && sums && dpred && bounds && weights && B > 0 && T > 1, "vq_losses: bad argument");
+  PT_CHECK(!l1 || t_nmask > 0.f, "masked_l1_losses: no unmasked frame");
+  PT_CHECK(nparts >= 1 && nparts <= 4, "vq_losses: 1..4 parts, got %d", nparts);
+  VqLossArgs a{};
+  a.pred = pred; a.ldp = ldp; a.gt = gt; a.ldg = ldg; a.dpred = dpred; a.lddp = lddp;
+  a.B = B; a.T = T; a.nparts = nparts; a.vel_cols = vel_cols; a.beta = beta; a.sums = sums;
+  a.nmask = nmask; a.l1 = l1;
+  for (int i = 0; i <= nparts; ++i) a.bounds[i] = bounds[i];
+  a.C = bounds[nparts];
+  PT_CHECK(bounds[0] == 0 && a.C <= ldp && a.C <= ldg && a.C <= lddp && vel_cols >= 0 && vel_cols <= a.C, "vq_losses: bad column ranges");
+  for (int i = 0; i < nparts; ++i) {
+    PT_CHECK(bounds[i + 1] > bounds[i], "vq_losses: empty part %d", i);
+    a.w[i] = weights[i];
+    a.inv_cnt[i] = (float)(1.0 / ((l1 ? (double)t_nmask : (double)B * T) * (bounds[i + 1] - bounds[i])));
+  }
+  a.inv_vel = vel_cols > 0 ? (float)(1.0 / ((double)B * (T - 1) * vel_cols)) : 0.f;
+  PT_HIP(hipMemsetAsync(sums, 0, sizeof(float) * (nparts + 2), s));
+  PT_LAUNCH(vq_loss_kernel, dim3(ew_blocks((size_t)B * T * a.C)), dim3(256), 0, s, a);
+  return 0;
+}
+
+// commitment loss pieces: *out += sum (a-b)^2 ;  dz = dq + (*g) * coef * (z - q)
+__global__ __launch_bounds__(256) void sqdiff_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                     float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const float d = a[e] - b[e];
+    acc += d * d;
+  }
+  acc = wsum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void commit_bwd_kernel(const float* __restrict__ dq, const float* __restrict__ z,
+                                                         const float* __restrict__ q, const float* __restrict__ g, float coef,
+                                                         size_t n, float* __restrict__ dz) {
+  const float c = (g ? *g : 1.f) * coef;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256)
+    dz[e] = (dq ? dq[e] : 0.f) + c * (z[e] - q[e]);
+}
+int launch_sqdiff(const float* a, const float* b, size_t n, float* out, hipStream_t s) {
+  PT_CHECK(a && b && out && n > 0, "sqdiff: bad argument");
+  PT_LAUNCH(sqdiff_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, a, b, n, out);
+  return 0;
+}
+int launch_commit_bwd(const float* dq, const float* z, const float* q, const float* g, float coef, size_t n, float* dz,
+                      hipStream_t s) {
+  PT_CHECK(z && q && dz && n > 0, "commit_bwd: bad argument");
+  PT_LAUNCH(commit_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dq, z, q, g, coef, n, dz);
   return 0;
 }
 

@@ -1,10 +1,11 @@
-"""`s2g_body_refiner` wrapper mirror (nets/inpainting/refiner.py:33-620), inference side."""
+"""`s2g_body_refiner` wrapper mirror (nets/inpainting/refiner.py:33-620)."""
 import time
 
+import numpy as np
 import torch
 import torch.nn as nn
-import torch.optim as optim
 
+from .. import train_ops, training
 from .base import TrainWrapperBaseClass
 from .modules import VQVAE_SC
 from .transformer_modules import RTransformer, interp_blend
@@ -48,13 +49,22 @@ class TrainWrapper(TrainWrapperBaseClass):
         self.in_dim = in_dim
         self.vq_dim = vq_dim
         self.discriminator = None
+        fix = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 21, 22, 23, 24, 25, 26, 30, 31, 32, 33, 34, 35]
+        keep = [i for i in range(165) if i not in fix]        # data_utils/lower_body.py:43-63
+        self.c_index = np.asarray([v for i in keep for v in (2 * i, 2 * i + 1)] if self.convert_to_6d else keep)
+        L = self.config.Data.pose.generate_length
+        self.random_mask = torch.zeros([L - 29, 1, L])         # refiner.py:103-106
+        for i in range(self.random_mask.shape[0]):
+            self.random_mask[i, 0, i:(i + 30)] = 1
+        self.train_dropout = 0.1
+        self._seeds = train_ops._Seeds(1)
         super().__init__(args, config)
 
     def to_parallel(self):
         pass
 
     def init_optimizer(self):
-        self.generator_optimizer = optim.AdamW(
+        self.generator_optimizer = train_ops.AdamW(
             [{'params': self.RTransformer.parameters()}, {'params': self.AudEnc.parameters()}],
             lr=self.config.Train.learning_rate.generator_learning_rate, betas=[0.9, 0.99])
 
@@ -73,7 +83,60 @@ class TrainWrapper(TrainWrapperBaseClass):
             self.generator_optimizer.load_state_dict(state_dict['generator_optim'])
 
     def __call__(self, bat):
-        raise NotImplementedError("s2g_body_refiner training step is not built yet")
+        """One refiner training step (refiner.py:183-311) on the HIP training kernels: frozen PQ-VAE reconstruction of
+        the ground truth (+ 0.05 N(0,1) augmentation) as the coarse input, 30-frame context mask, RTransformer train
+        forward, masked part-L1 + velocity loss, backward, clipping, AdamW.  Test hooks in `bat`: '_mask' (B,1,T),
+        '_noise' (B,C,T) replace the two random draws."""
+        self.global_step += 1
+        if self.type != 'fbhe' or self.vqtype != 'fbhe':
+            raise NotImplementedError("refiner training is built for hf_type = hf_vq_type = 'fbhe' (config/transformer.json)")
+        dev = 'cuda'
+        aud = bat['aud_feat'].to(dev).to(torch.float32)
+        poses = bat['poses'].to(dev).to(torch.float32)
+        expression = bat['expression'].to(dev).to(torch.float32)
+        id = bat['speaker'].to(dev)
+        jaw = poses[:, :self.each_dim[0], :]
+        gt_poses = torch.cat([jaw, poses[:, self.c_index, :], expression], dim=1).contiguous()
+        bs, n, t = gt_poses.size()
+        if '_mask' in bat:
+            mask = bat['_mask'].to(dev).to(torch.float32)
+        elif self.motion_context:
+            select = torch.randint(0, self.random_mask.shape[0], (bs,))
+            mask = self.random_mask[select].clone()
+            mask[:64] = 0
+            mask = mask.to(dev)
+        else:
+            mask = torch.zeros([bs, 1, t], device=dev)
+        with torch.no_grad():
+            self.VQ.eval()
+            vq_poses = self.VQ(gt_poses=gt_poses)
+            noise = bat['_noise'].to(dev) if '_noise' in bat else torch.randn(bs, n, t, device=dev)
+            # F.interpolate(vq, t) + 0.05*noise, then gt*mask + (.)*(1-mask)  (refiner.py:247,267-270)
+            coarse = interp_blend(vq_poses, t, torch.zeros_like(gt_poses), torch.zeros_like(mask), premask=False)
+            input_poses = gt_poses * mask + (coarse + 0.05 * noise) * (1 - mask)
+        rt = self.RTransformer
+        if next(rt.parameters()).device.type != 'cuda':
+            rt.cuda()
+        rt.train()
+        P = training.tensors_of(rt)
+        self.generator_optimizer.zero_grad()
+        loss, sums, _ = training.refiner_loss(P, aud, input_poses, gt_poses, mask, id.reshape(-1), p_drop=self.train_dropout,
+                                              seeds=self._seeds)
+        loss.backward()
+        params = list(rt.parameters())
+        if torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            if self.__dict__.get('_reducer') is None:
+                from ..dist import GradientReducer
+                self._reducer = GradientReducer(params, list(rt.buffers()))
+            self._reducer.reduce()
+        grad_HF, coef = train_ops.clip_grad_norm(params, self.config.Train.max_gradient_norm)
+        self.generator_optimizer.step({p: coef for p in params})
+        rt.invalidate()
+        s = sums.tolist()
+        loss_dict = {'face_loss': s[0], 'body_loss': s[1], 'rec_loss': (s[0] + s[1] + s[2] + s[3]) / 4, 'velocity_loss': s[4],
+                     'loss': loss.item(), 'grad_HF': grad_HF.item(), 'grad_A': 0.0}
+        return None, loss_dict
 
     def infer_on_batch(self, aud, B, id, gt_poses, mask, pred_poses=None, sync=True, **kwargs):
         """refiner.py:512-558 -> (poses (B,C,T), seconds)."""

@@ -1,9 +1,10 @@
-"""`s2g_body_vqt` wrapper mirror (nets/inpainting/vq_teacher.py:37-285), inference side."""
+"""`s2g_body_vqt` wrapper mirror (nets/inpainting/vq_teacher.py:37-285)."""
 import time
 
+import numpy as np
 import torch
-import torch.optim as optim
 
+from .. import train_ops, training
 from .base import TrainWrapperBaseClass
 from .modules import VQVAE_SC
 
@@ -30,12 +31,18 @@ class TrainWrapper(TrainWrapperBaseClass):
                            num_residual_layers=2, num_residual_hiddens=512, q_type=config.Model.q_type,
                            groups=config.Model.groups, share_code=config.Model.share_code)
         self.discriminator = None
+        self.in_dim = in_dim
+        # data_utils/lower_body.py:43-63 (see predictor.py)
+        fix = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 21, 22, 23, 24, 25, 26, 30, 31, 32, 33, 34, 35]
+        keep = [i for i in range(165) if i not in fix]
+        self.c_index = np.asarray([v for i in keep for v in (2 * i, 2 * i + 1)] if self.convert_to_6d else keep)
         super().__init__(args, config)
 
     def init_optimizer(self):
-        self.generator_optimizer = optim.Adam([{'params': self.VQ.parameters()}],
-                                              lr=self.config.Train.learning_rate.generator_learning_rate,
-                                              betas=[0.9, 0.999])
+        # optim.Adam(betas 0.9/0.999) (vq_teacher.py:97-101) = the AdamW kernel with weight decay 0
+        self.generator_optimizer = train_ops.AdamW([{'params': self.VQ.parameters()}],
+                                                   lr=self.config.Train.learning_rate.generator_learning_rate,
+                                                   betas=[0.9, 0.999], weight_decay=0.0)
 
     def state_dict(self):
         return {'VQ': self.VQ.state_dict(), 'generator_optim': self.generator_optimizer.state_dict()}
@@ -46,8 +53,68 @@ class TrainWrapper(TrainWrapperBaseClass):
         if 'generator_optim' in state_dict:
             self.generator_optimizer.load_state_dict(state_dict['generator_optim'])
 
+    def _loss_spec(self):
+        """(column bounds, weights, velocity columns) of get_loss (vq_teacher.py:191-226) per vq_type."""
+        d, e = self.dim_list, self.each_dim
+        if self.type == 'fbhe':
+            return [0, d[1], d[3], d[4], self.in_dim], [0.5 - 0.4, 0.4, 0.4, 0.5 - 0.4], ('face_loss', 'body_loss', 'hand_loss', 'exp_loss')
+        if self.type == 'bh':
+            return [0, e[1], self.in_dim], [0.5, 0.5], ('body_loss', 'hand_loss')
+        return [0, d[1] - d[0], self.in_dim], [0.5, 0.5], ('jaw_loss', 'exp_loss')
+
     def __call__(self, bat):
-        raise NotImplementedError("s2g_body_vqt training step (EMA codebook update, losses) is not built yet")
+        """One PQ-VAE training step (vq_teacher.py:135-182) on the HIP training kernels: encoder / decoder with
+        batch-statistic BatchNorm, nearest-code search, commitment loss + straight-through estimator, EMA codebook
+        update with dead-code re-seeding, part-weighted smooth-L1 + velocity losses, backward, Adam.
+        The reference clips gradients BEFORE loss.backward() (173 vs 177): the call sees zeroed/absent gradients, so it
+        never scales anything and `grad` is always 0; that behaviour is kept."""
+        self.global_step += 1
+        dev = 'cuda'
+        poses = bat['poses'].to(dev).to(torch.float32)
+        expression = bat['expression'].to(dev).to(torch.float32)
+        jaw = poses[:, :self.each_dim[0], :]
+        poses = poses[:, self.c_index, :]
+        if self.type == 'fbhe':
+            poses = torch.cat([jaw, poses, expression], dim=1)
+        elif self.type == 'fe':
+            poses = torch.cat([jaw, expression], dim=1)
+        gt_poses = poses.contiguous()
+        bs, n, t = gt_poses.size()
+        vq = self.VQ
+        if next(vq.parameters()).device.type != 'cuda':
+            vq.cuda()
+        vq.train()
+        P = training.tensors_of(vq)
+        ql = vq.vq_layer
+        G = ql.num_chunks
+        cb = torch.stack([getattr(ql, f'embeddings_{i}') for i in range(G)]).contiguous()
+        gt_rows = train_ops.ncl_to_rows(gt_poses)
+        self.generator_optimizer.zero_grad()
+        z, e_q_loss, idx, pred, t_out = training.vqvae_train_forward(P, cb, gt_rows, bs, t, ql.commitment_cost)
+        if t_out != t:
+            raise RuntimeError(f"PQ-VAE training needs T divisible by 8 (got {t}: decoder returns {t_out})")
+        # EMA codebook update (no gradient); the decoder above used the OLD codes, as the reference does
+        cs = torch.stack([m.hidden for m in ql.ema_cluster_size]).contiguous()
+        dw = torch.stack([m.hidden for m in ql.ema_dw]).contiguous()
+        for m in list(ql.ema_cluster_size) + list(ql.ema_dw):
+            m.counter += 1
+        train_ops.pq_ema_update(z.detach(), idx, cs, dw, cb, ql.ema_dw[0].decay, ql.epsilon, ql.ema_dw[0].counter)
+        for i in range(G):
+            ql.ema_cluster_size[i].hidden.copy_(cs[i])
+            ql.ema_dw[i].hidden.copy_(dw[i])
+            getattr(ql, f'embeddings_{i}').copy_(cb[i])
+        ql.__dict__['_pt_cb'] = None
+        bounds, weights, names = self._loss_spec()
+        vel_cols = n - self.each_dim[3]
+        rec, sums = train_ops.VQLosses.apply(pred, gt_rows, bs, t, bounds, weights, vel_cols, 0.01)
+        loss = rec + e_q_loss
+        loss.backward()
+        self.generator_optimizer.step()
+        vq.invalidate()
+        s = sums.tolist()
+        loss_dict = {k: s[i] for i, k in enumerate(names)}
+        loss_dict.update({'velocity_loss': s[len(names)], 'e_q_loss': e_q_loss.item(), 'q_loss': 0, 'lr_loss': 0, 'grad': 0.0})
+        return None, loss_dict
 
     def infer_on_audio(self, gt_poses, aud, text, id, B, **kwargs):
         """vq_teacher.py:255-275: encode -> quantize -> decode, (poses, seconds)."""

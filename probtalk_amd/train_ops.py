@@ -376,6 +376,95 @@ def ncl_to_rows(x_ncl, width=None):
     return out
 
 
+class PQQuantizeTrain(torch.autograd.Function):
+    """ProductQuantization.forward in train mode, the differentiable part (vqvae_modules.py:470-487,536-544): nearest
+    codes per sub-codebook (same fp32 search kernel as inference), commitment loss cc * mse(z, q), straight-through
+    estimator.  z rows [B*W, G*D]; returns (q rows, loss, indices (B*W, G) int64)."""
+
+    @staticmethod
+    def forward(ctx, z, codebooks, commitment_cost):
+        L = _lib.lib()
+        rows, Cc = z.shape
+        G, K, D = codebooks.shape
+        q = _empty(rows, Cc)
+        idx = torch.empty(rows, G, dtype=torch.int64, device=z.device)
+        check(L.pt_pq_search_cl(ptr(z), Cc, ptr(codebooks), rows, G, D, K, ptr(idx), ptr(q), Cc, stream()))
+        ss = _zeros(1)
+        check(L.pt_train_sqdiff(ptr(z), ptr(q), z.numel(), ptr(ss), stream()))
+        ctx.save_for_backward(z, q)
+        ctx.cc = float(commitment_cost)
+        ctx.mark_non_differentiable(idx)
+        return q, ss[0] * (ctx.cc / z.numel()), idx
+
+    @staticmethod
+    def backward(ctx, dq, dloss, _didx):
+        z, q = ctx.saved_tensors
+        L = _lib.lib()
+        dz = _empty(z.shape)
+        g = dloss.reshape(1).contiguous() if dloss is not None else None
+        dqc = dq.contiguous() if dq is not None else None
+        check(L.pt_train_commit_bwd(ptr(dqc), ptr(z), ptr(q), ptr(g), 2.0 * ctx.cc / z.numel(), z.numel(), ptr(dz), stream()))
+        return dz, None, None
+
+
+def pq_ema_update(z, idx, cs_hidden, dw_hidden, emb, decay, eps, counter):
+    """EMA codebook update + dead-code re-seeding (vqvae_modules.py:513-534) in place on the stacked buffers
+    cs_hidden [G,K], dw_hidden [G,K,D], emb [G,K,D]; z rows are the encoder output of this step, idx its codes."""
+    L = _lib.lib()
+    G, K, D = emb.shape
+    counts, dw = _empty(G, K), _empty(G, K, D)
+    check(L.pt_train_pq_ema(ptr(z), z.shape[1], ptr(idx), z.shape[0], G, D, K, ptr(counts), ptr(dw), ptr(cs_hidden),
+                            ptr(dw_hidden), ptr(emb), float(decay), float(eps), int(counter), stream()))
+
+
+class VQLosses(torch.autograd.Function):
+    """vq_teacher.get_loss (vq_teacher.py:184-232) without the commitment term: weighted smooth-L1 part losses +
+    velocity L1.  Returns (total, sums) with sums = part means | velocity mean | total (device tensor, no gradient)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, B, Tn, bounds, weights, vel_cols, beta):
+        import ctypes as C
+        L = _lib.lib()
+        nparts = len(weights)
+        sums = _zeros(nparts + 2)
+        dpred = _zeros(pred.shape)
+        check(L.pt_train_vq_losses(ptr(pred), pred.shape[1], ptr(gt), gt.shape[1], B, Tn, nparts,
+                                   (C.c_int * (nparts + 1))(*bounds), (C.c_float * nparts)(*weights), vel_cols, beta,
+                                   ptr(sums), ptr(dpred), dpred.shape[1], stream()))
+        ctx.save_for_backward(dpred)
+        ctx.mark_non_differentiable(sums)
+        return sums[nparts + 1].clone(), sums
+
+    @staticmethod
+    def backward(ctx, g, _gs):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g, None, None, None, None, None, None, None
+
+
+class MaskedL1Losses(torch.autograd.Function):
+    """refiner.get_loss (refiner.py:313-391): per-part L1 over the unmasked frames, weighted, + velocity L1.
+    nmask: (B*T,) = 1 - mask per frame row.  Returns (total, sums) like VQLosses."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, nmask, t_nmask, B, Tn, bounds, weights, vel_cols):
+        import ctypes as C
+        L = _lib.lib()
+        nparts = len(weights)
+        sums = _zeros(nparts + 2)
+        dpred = _zeros(pred.shape)
+        check(L.pt_train_masked_l1_losses(ptr(pred), pred.shape[1], ptr(gt), gt.shape[1], ptr(nmask), float(t_nmask), B, Tn,
+                                          nparts, (C.c_int * (nparts + 1))(*bounds), (C.c_float * nparts)(*weights),
+                                          vel_cols, ptr(sums), ptr(dpred), dpred.shape[1], stream()))
+        ctx.save_for_backward(dpred)
+        ctx.mark_non_differentiable(sums)
+        return sums[nparts + 1].clone(), sums
+
+    @staticmethod
+    def backward(ctx, g, _gs):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g, None, None, None, None, None, None, None, None
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # optimizer side: torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW semantics on HIP kernels
 # ---------------------------------------------------------------------------------------------------------------

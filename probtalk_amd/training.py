@@ -41,7 +41,7 @@ def cond_encoder_train(P, x_rows, B, Tn, p_drop, seeds, prefix=""):
 
 
 # ------------------------------------------------------------------------------------------- motion-context encoder
-relu_trace = None      # tests set this to a list to receive each FFN's post-ReLU activations (which side of 0 a unit fell)
+relu_trace = None      # tests set this to a list to receive every (Leaky)ReLU output in call order (which side of 0 a unit fell)
 
 GATED_KIND = [2, 1, 3, 1, 3, 1, 3, 1, 1, 1]     # enc.0 .. enc.9: k7 | k3 | k4 s2 | ... (predictornet.py:36-49)
 
@@ -140,3 +140,89 @@ def predictor_loss(Pa, Pp, aud, input_poses, mask, label, state, keep_scores, ep
     loss = T.CrossEntropy.apply(logits[:, :Pp["decoder.output_conv.2.weight"].shape[0]].contiguous(),
                                 state.reshape(-1).to(torch.int64).contiguous())
     return loss, logits
+
+
+# ------------------------------------------------------------------------------------------- PQ-VAE (vq_teacher)
+def _cnr(P, p, x, B, L, sample="none", residual=False):
+    """ConvNormRelu in train mode (vqvae_modules.py:193-200): LeakyReLU(0.2)(BN_batch(conv(x)) [+ residual_layer(x)])."""
+    kind = {"none": 1, "down": 3, "up": 4}[sample]
+    c = T.conv(x, P[p + "conv.weight"], P[p + "conv.bias"], kind, B, L)
+    r = T.conv(x, P[p + "residual_layer.weight"], P[p + "residual_layer.bias"], kind, B, L) if residual else None
+    y = T.bn_train(c, P[p + "norm.weight"], P[p + "norm.bias"], P[p + "norm.running_mean"], P[p + "norm.running_var"],
+                   slope=0.2, res=r)
+    if relu_trace is not None:
+        relu_trace.append(y.detach())
+    return y, {"none": L, "down": (L - 2) // 2 + 1, "up": 2 * L}[sample]
+
+
+def _res_stack(P, p, x, B, L, layers=2):
+    """Res_CNR_Stack (vqvae_modules.py:238-245): relu(BN(conv(layers(x))) + x)."""
+    h = x
+    for i in range(layers):
+        h, _ = _cnr(P, f"{p}_layers.{i}.", h, B, L)
+    c = T.conv(h, P[p + "conv.weight"], P[p + "conv.bias"], 1, B, L)
+    y = T.bn_train(c, P[p + "norm.weight"], P[p + "norm.bias"], P[p + "norm.running_mean"], P[p + "norm.running_var"],
+                   slope=0.0, res=x)
+    if relu_trace is not None:
+        relu_trace.append(y.detach())
+    return y
+
+
+def encoder_sc_train(P, x_rows, B, L, p="encoder."):
+    """EncoderSC.forward (vqvae_1d_sc.py:220-235) in train mode: rows (B*T, 384) -> z rows (B*T/8, 512)."""
+    h, L = _cnr(P, p + "project.", x_rows, B, L)
+    h = _res_stack(P, p + "_enc_1.", h, B, L)
+    for i in (1, 2, 3):
+        h, L = _cnr(P, f"{p}_down_{i}.", h, B, L, "down", True)
+        h = _res_stack(P, f"{p}_enc_{i + 1}.", h, B, L)
+    return T.conv(h, P[p + "pre_vq_conv.weight"], P[p + "pre_vq_conv.bias"], 0, B, L), L
+
+
+def decoder_sc_train(P, e_rows, B, L, p="decoder."):
+    """DecoderSC.forward (vqvae_1d_sc.py:259-274) in train mode: rows (B*T', 512) -> rows (B*8T', 384)."""
+    h = T.conv(e_rows, P[p + "aft_vq_conv.weight"], P[p + "aft_vq_conv.bias"], 0, B, L)
+    h = _res_stack(P, p + "_dec_1.", h, B, L)
+    for i in (2, 3, 4):
+        h, L = _cnr(P, f"{p}_up_{i}.", h, B, L, "up", True)
+        h = _res_stack(P, f"{p}_dec_{i}.", h, B, L)
+    return T.conv(h, P[p + "project.weight"], P[p + "project.bias"], 0, B, L), L
+
+
+def vqvae_train_forward(P, codebooks, x_rows, B, Tn, commitment_cost=0.25):
+    """VQVAE_SC.forward(result_form='full') in train mode, without the EMA side effect (run `T.pq_ema_update` on the
+    returned z / indices afterwards): -> (z rows, commitment loss, indices, pred rows, T_out)."""
+    z, Tq = encoder_sc_train(P, x_rows, B, Tn)
+    q, e_q_loss, idx = T.PQQuantizeTrain.apply(z, codebooks, commitment_cost)
+    pred, Tout = decoder_sc_train(P, q, B, Tq)
+    return z, e_q_loss, idx, pred, Tout
+
+
+# ------------------------------------------------------------------------------------------- refiner
+def rtransformer_train(P, x_rows, cond_rows, label, B, Tn, p_drop, seeds):
+    """RTransformer.forward in train mode (RTransformer.py:209-230): x rows (B*T, 384) poses, cond rows (B*T, 800) =
+    audio 768 | one-hot(mask) 2 -> rows (B*T, 384)."""
+    pe = P["PE.position_encoding.weight"][1:Tn + 1].to(torch.float32).repeat(B, 1).contiguous()
+    x = T.conv(x_rows, P["input_conv.weight"], P["input_conv.bias"], 0, 1, B * Tn, res=pe)
+    mem = T.conv(cond_rows, P["audio_conv.weight"], P["audio_conv.bias"], 0, 1, B * Tn, res=pe)
+    ce = P["class_embed.weight"]
+    silu_ce = ce * torch.sigmoid(ce)
+    n_layers = 0
+    while f"transformer_decoder.layers.{n_layers}.norm1.weight" in P:
+        n_layers += 1
+    for i in range(n_layers):
+        x = decoder_layer_train(P, f"transformer_decoder.layers.{i}.", x, mem, silu_ce, label, B, Tn, Tn, p_drop, seeds)
+    h = T.conv(x, P["output_conv.0.weight"], P["output_conv.0.bias"], 0, 1, B * Tn, slope=0.0)
+    return T.conv(h, P["output_conv.2.weight"], P["output_conv.2.bias"], 0, 1, B * Tn)
+
+
+def refiner_loss(P, aud, input_poses, gt_poses, mask, label, p_drop=0.0, seeds=None, bounds=(0, 6, 96, 276, 376),
+                 weights=(0.25, 0.25, 0.25, 0.25), vel_cols=276):
+    """refiner.py:296-297: RTransformer forward + get_loss -> (loss, sums, pred rows)."""
+    B, _, Tn = aud.shape
+    x_rows = T.ncl_to_rows(input_poses)
+    cond_rows = T.ncl_to_rows(torch.cat([aud, 1.0 - mask, mask], dim=1))          # F.one_hot(mask, 2): [mask==0 | mask==1]
+    pred = rtransformer_train(P, x_rows, cond_rows, label.to(torch.int64).contiguous(), B, Tn, p_drop, seeds)
+    nmask = (1.0 - mask).reshape(-1).contiguous()
+    loss, sums = T.MaskedL1Losses.apply(pred, T.ncl_to_rows(gt_poses), nmask, float(nmask.sum()), B, Tn, list(bounds),
+                                        list(weights), vel_cols)
+    return loss, sums, pred

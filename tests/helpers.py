@@ -60,3 +60,43 @@ TRAIN_GRAD_KEYS = [
     ("Predictor", "decoder.transformer_decoder.layers.5.style_gourp_3.out_layers_2.2.bias"),
     ("Predictor", "decoder.output_conv.2.bias"),
 ]
+
+# gradients stored in tests/golden/vq_train_b12_t88.npz as grad_<i> (tools/make_golden_vq_train.py)
+VQ_TRAIN_GRAD_KEYS = [
+    "encoder.project.conv.weight", "encoder.project.norm.weight", "encoder._enc_1._layers.0.conv.weight",
+    "encoder._enc_2.norm.bias", "encoder._down_2.residual_layer.weight", "encoder._down_3.conv.bias",
+    "encoder._enc_4.conv.weight", "encoder.pre_vq_conv.weight", "encoder.pre_vq_conv.bias",
+    "decoder.aft_vq_conv.weight", "decoder._dec_1._layers.1.norm.weight", "decoder._up_2.conv.weight",
+    "decoder._up_3.residual_layer.bias", "decoder._dec_3.conv.weight", "decoder._up_4.norm.bias",
+    "decoder._dec_4._layers.0.conv.bias", "decoder.project.weight", "decoder.project.bias",
+]
+
+# gradients stored in tests/golden/refiner_train_b2_t64.npz as grad_<i> (tools/make_golden_refiner_train.py)
+REFINER_TRAIN_GRAD_KEYS = [
+    "input_conv.weight", "input_conv.bias", "audio_conv.weight", "class_embed.weight",
+    "transformer_decoder.layers.0.self_attn.in_proj_weight", "transformer_decoder.layers.0.norm1.weight",
+    "transformer_decoder.layers.1.multihead_attn.in_proj_bias", "transformer_decoder.layers.2.linear1.bias",
+    "transformer_decoder.layers.3.style_gourp_2.emb_layers_2.1.weight",
+    "transformer_decoder.layers.4.style_gourp_3.out_layers_2.2.weight", "transformer_decoder.layers.5.norm3.bias",
+    "output_conv.0.weight", "output_conv.2.bias",
+]
+
+
+REFINER_TRAIN_TAG = "1"
+
+
+def refiner_train_case(tag=None):
+    """(aud, input_poses, gt_poses, mask, label) of the refiner train fixture: B=2, T=64, one clip with a 30-frame
+    context window; input = gt*mask + (gt + noise)*(1-mask), the shape of refiner.py:267-270.  The input tag was picked
+    (tools/make_golden_refiner_train.py --search) so that no ReLU unit of the six FFNs sits within fp32 rounding of 0:
+    the reference's nn.MultiheadAttention and the oracle's explicit attention round differently, and one such unit
+    flipping side changes every upstream gradient at the 1e-3 level."""
+    from probtalk_amd.weights import make_input
+    tag = REFINER_TRAIN_TAG if tag is None else tag
+    B, T = 2, 64
+    aud = make_input(f"rtrain{tag}.aud", (B, 768, T))
+    gt = make_input(f"rtrain{tag}.gt", (B, 376, T))
+    mask = torch.zeros(B, 1, T)
+    mask[1, :, 10:40] = 1
+    vq = gt + 0.3 * make_input(f"rtrain{tag}.vq", (B, 376, T))
+    return aud, gt * mask + vq * (1 - mask), gt, mask, torch.tensor([1, 3])
