@@ -170,6 +170,9 @@ def test_vq_train_step_matches_oracle_and_fixture():
     for i, k in enumerate(VQ_TRAIN_GRAD_KEYS):
         got = P[k].grad.cpu()
         got = got[:4] if got.numel() > 20000 else got
+        if float(np.abs(gold[f"grad_{i}"]).max()) < 1e-6 * gmax:    # conv bias in front of batch-stat BN: exact gradient
+            assert float(got.abs().max()) < 1e-5 * gmax, k          # is 0, both sides hold rounding noise only
+            continue
         assert rel_err(got, gold[f"grad_{i}"]) < (5e-4 if flips == 0 else 5e-2), k
     # EMA side effects and BatchNorm running statistics
     cs = torch.stack([P[f"vq_layer.ema_cluster_size.{i}.hidden"] for i in range(4)]).contiguous()
