@@ -29,7 +29,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak (
 MFLOP_PER_FRAME = 296.0          # full pipeline, algorithmic (2*MAC of the reference modules)
 
 
-def cpu_baseline(B=2, T=300, runs=3):
+def cpu_baseline(B=32, T=300, runs=3):
     """The CPU oracle ("port") on a bounded sample of the same workload, on this box's host cores."""
     from oracle import probtalk_oracle as O
     from probtalk_amd.weights import make_input

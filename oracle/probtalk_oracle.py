@@ -405,3 +405,50 @@ def refiner_infer(sd_ref, aud, gt_poses, mask, label, pred_poses):
     blank = gt_poses * mask + torch.zeros_like(pred) + pred * (1 - mask)
     out = rtransformer(sd_ref, blank, aud, mask, label)
     return gt_poses * mask + out * (1 - mask)
+
+
+# --------------------------------------------------------------------------
+# sliding-window callers of the path (scripts/test_holisticbody.py:239-262; scripts/demo.py:113-178)
+# --------------------------------------------------------------------------
+def holistic_slices_infer(sd_aud, sd_pred, sd_vq, sd_ref, aud, gt_poses, mask, label, noises):
+    """test_holisticbody.py:239-262 with predictor -> refiner per slice (ai1.py:51-57).  aud (B,768,L) already repeated,
+    gt_poses (B,C,L), mask (B,1,L); noises[i] = (noise_q, noise_g) of slice i."""
+    L = aud.shape[-1]
+    num_slices = 1 + math.ceil((L - 180) / 150)
+    input_gt, input_mask, pred = gt_poses.clone(), mask.clone(), None
+    for i in range(num_slices):
+        s = 0 if i == 0 else 150 + 180 * (i - 1)
+        e = 180 if i == 0 else 150 + 180 * i
+        a, g, m = aud[..., s:e], input_gt[..., s:e], input_mask[..., s:e]
+        body, _ = predictor_infer(sd_aud, sd_pred, sd_vq, a, g, m, label, noises[i][0], noises[i][1])
+        pred_0 = refiner_infer(sd_ref, a, g, m, label, body)
+        pred = pred_0 if pred is None else torch.cat([pred, pred_0[..., 30:]], -1)
+        input_gt[..., s:e] = pred_0
+        input_mask[..., s:e] = 1
+    return gt_poses * mask + pred * (1 - mask)
+
+
+def demo_slices_infer(sd_aud, sd_pred, sd_vq, sd_ref, aud, label, noises, C=376):
+    """demo.py:113-178: predictor codes per 180-frame slice (stride 150), ONE decode of the joined code grid, refiner over
+    176-frame slices (stride 146).  Returns (refined, preliminary_motion, codes)."""
+    B, _, t = aud.shape
+    input_gt, input_mask = torch.zeros(B, C, t), torch.zeros(B, 1, t)
+    code_list = []
+    for i in range(math.ceil((t - 30) / 150)):
+        s, e = 150 * i, 150 * i + 180
+        pred_0, codes = predictor_infer(sd_aud, sd_pred, sd_vq, aud[..., s:e], input_gt[..., s:e], input_mask[..., s:e], label,
+                                        noises[i][0], noises[i][1])
+        code_list.append(codes)
+        input_gt[..., s:e] = pred_0
+        input_mask[..., s:e] = 1
+    codes = torch.cat([code_list[0]] + [c[:, 3:] for c in code_list[1:]], dim=1)
+    prelim = vqvae_decode(sd_vq, pq_quantize_all(sd_vq, "vq_layer.", codes).transpose(1, 2))
+    prelim = F.interpolate(prelim, size=t, mode="linear")
+    input_mask, pred_all = torch.zeros(B, 1, t), None
+    for i in range(math.ceil((t - 30) / 146)):
+        s, e = 146 * i, 146 * i + 176
+        pred_0 = refiner_infer(sd_ref, aud[..., s:e], input_gt[..., s:e], input_mask[..., s:e], label, prelim[..., s:e])
+        pred_all = pred_0 if pred_all is None else torch.cat([pred_all, pred_0[..., 30:]], -1)
+        input_gt[..., s:e] = pred_0
+        input_mask[..., s:e] = 1
+    return pred_all, prelim, codes
