@@ -1,0 +1,287 @@
+// Phase-pipelined 256 x 256 bf16 GEMM for the wide transformer Linears (in-proj 512->1536, FFN-1 512->2048,
+// cross K/V 512->1024, heads): C[M,N] = A[M,K] . W[N,K]^T, bf16 operands, fp32 accumulation.
+//
+// 512 threads = 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4 v_mfma_f32_16x16x32_bf16 accumulators.
+// A K-tile (BK = 64) is staged by LDS-DMA (global_load_lds_dwordx4) as FOUR half-tile images of 128 rows x 128 B:
+//   h0 / h1 = the 64-row halves mh = 0 / 1 of every wave's A rows,  h2 / h3 = the 32-column halves nh = 0 / 1 of every
+//   wave's W rows, two K-tile buffers (2 x 4 x 16 KB = 128 KB) + 8 wave-private 4 KB store slabs = 160 KB.
+// A K-tile is four phases of 16 MFMAs, one output quadrant (mh, nh) x K = 64 each:
+//   P1 reads B(nh0) + A(mh0), MFMA (0,0);  P2 reads B(nh1), MFMA (0,1);  P3 reads A(mh1), MFMA (1,1);  P4 MFMA (1,0).
+// Every phase is  [ds_reads | DMA issue of ONE half-tile | counted vmcnt]  s_barrier  [16 MFMAs]  s_barrier, and
+// waves 4-7 run one barrier behind waves 0-3: the two waves that share a SIMD alternate between the read/DMA segment
+// and the MFMA segment, so the matrix pipe always has a wave to issue from (MI355X_MICROARCH.md, two waves per SIMD).
+//
+// DMA schedule (phase p of K-tile t): P1 -> h3 of t+1, P2 -> h1 of t+1, P3 -> h0 of t+2, P4 -> h2 of t+2: a half-tile
+// is re-filled two phases or more after its last read (WAR), is retired by the counted wait four phases after its issue
+// (vmcnt(8) = four half-tiles of 2 DMA instructions stay in flight) and is read five or six phases after its issue,
+// i.e. at least one phase and one barrier after every wave's retiring wait (RAW across the staggered halves).
+// The K-tile stream runs across output tiles (persistent workgroups): the next tile's first K-tiles land while the
+// current tile's accumulators are stored.  Stores share the vmcnt counter with the DMA, so a tile ends with vmcnt(0)
+// BEFORE its stores and the next tile's first K-tile issues no waits (everything it reads has landed by then).
+#include <cstdlib>
+
+#include "pt_common.h"
+
+namespace pt {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+void prof_record_begin(hipStream_t s, double flops, int cfg, void** tok);
+void prof_record_end(hipStream_t s, void* tok);
+bool prof_is_on();
+
+constexpr int G8_HT = 128 * 128;          // bytes of a half-tile image (128 rows x 64 bf16)
+constexpr int G8_STAGE = 4 * G8_HT;       // one K-tile buffer
+constexpr int G8_SLAB = 4096;             // wave-private store slab
+constexpr int G8_SMEM = 2 * G8_STAGE + 8 * G8_SLAB;
+
+__global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const int tiles_n, const int ntiles) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int G = gridDim.x;
+  int tile0;
+  {
+    const int q = G >> 3, rr = G & 7, x = blockIdx.x & 7;       // bijective XCD-aware order (see gemm_bf16_big.hip)
+    tile0 = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + (blockIdx.x >> 3);
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  if (p.stagger > 0) {
+    // spread the workgroups' start times: left alone, all 256 CUs run their main loops together and then store their
+    // tiles together, so the HBM write burst and the MFMA work serialise instead of overlapping
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long d = (unsigned long long)(((blockIdx.x >> 3) * 5 + (blockIdx.x & 7) * 2) & 15) * p.stagger >> 4;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(8);
+  }
+  const int r = lane & 15, q4 = lane >> 4;
+  const int nt = p.K >> 6;
+
+  // ---- per-half-tile DMA cursors (wave-uniform) and per-lane source offsets
+  int c_tile[4], c_kt[4], c_buf[4];
+  unsigned soff[4][2];
+  auto set_src = [&](int h, int tl) {
+    const int tm = tl / tiles_n, tn = tl - tm * tiles_n;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int lr = (wave + 8 * i) * 8 + (lane >> 3);              // local row of the half-tile image
+      const int g = (lane & 7) ^ ((lr >> 1) & 7);                   // source chunk (swizzle lives in the source address)
+      if (h < 2) {
+        int m = tm * 256 + (lr >> 6) * 128 + h * 64 + (lr & 63);
+        m = m < p.M ? m : p.M - 1;
+        soff[h][i] = ((unsigned)m * (unsigned)p.lda + g * 8) * 2u;
+      } else {
+        int n = tn * 256 + (lr >> 5) * 64 + (h - 2) * 32 + (lr & 31);
+        n = n < p.Npad ? n : p.Npad - 1;
+        soff[h][i] = ((unsigned)n * (unsigned)p.K + g * 8) * 2u;
+      }
+    }
+  };
+  bool draining = false;
+  auto issue = [&](int h) {
+    if (c_tile[h] >= ntiles) {
+      draining = true;
+      return;
+    }
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(h < 2 ? (const void*)p.A : (const void*)p.W) + (size_t)c_kt[h] * 128;
+    unsigned char* dst = smem + c_buf[h] * G8_STAGE + h * G8_HT + wave * 1024;
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + soff[h][0]), (lds_ptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + soff[h][1]), (lds_ptr_t)(dst + 8 * 1024), 16, 0, 0);
+    c_buf[h] ^= 1;
+    if (++c_kt[h] == nt) {
+      c_kt[h] = 0;
+      c_tile[h] += G;
+      if (c_tile[h] < ntiles) set_src(h, c_tile[h]);
+    }
+  };
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    c_tile[h] = tile0;
+    c_kt[h] = 0;
+    c_buf[h] = 0;
+    set_src(h, tile0);
+  }
+  // prologue: K-tile 0 whole, then h0 / h2 of K-tile 1 (the loop issues h3 / h1 of t+1 and h0 / h2 of t+2)
+  issue(0); issue(2); issue(3); issue(1); issue(0); issue(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();                    // waves 4-7 run one barrier behind
+
+  // fragment read offsets inside a half-tile image: row r, chunk (4 s + q4) ^ ((r >> 1) & 7)
+  int aoff[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) aoff[s] = r * 128 + (((4 * s + q4) ^ ((r >> 1) & 7)) << 4);
+  const int a_row0 = wr * 64 * 128, b_row0 = wc * 32 * 128;
+
+  f32x4 acc[8][4];
+  bf16x8 af[4][2], bfr[2][2][2];
+  int cbuf = 0;
+  unsigned char* slab = smem + 2 * G8_STAGE + wave * G8_SLAB;
+
+  int stamp_i = 0;
+  auto stamp = [&]() {
+    if (p.stamps && tid == 0 && stamp_i < 64 && blockIdx.x < 256) p.stamps[blockIdx.x * 64 + stamp_i++] = __builtin_amdgcn_s_memrealtime();
+  };
+  for (int tile = tile0; tile < ntiles; tile += G) {
+    stamp();                                             // [0] tile start
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < nt; ++t, cbuf ^= 1) {
+      const unsigned char* sb = smem + cbuf * G8_STAGE;
+      auto readA = [&](int mh) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            af[i][s] = *reinterpret_cast<const bf16x8*>(sb + mh * G8_HT + a_row0 + i * 2048 + aoff[s]);
+      };
+      auto readB = [&](int nh) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            bfr[nh][j][s] = *reinterpret_cast<const bf16x8*>(sb + (2 + nh) * G8_HT + b_row0 + j * 2048 + aoff[s]);
+      };
+      auto wait = [&]() {
+        if (t > 0) {
+          if (draining) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+      };
+      auto mma = [&](int mh, int nh) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[mh * 4 + i][nh * 2 + j] =
+                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nh][j][s], af[i][s], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+      };
+      // P1
+      readB(0); readA(0); issue(3); wait();
+      if (t == 1) stamp();                               // [1] first counted wait of the tile passed
+      mma(0, 0);
+      // P2
+      readB(1); issue(1); wait(); mma(0, 1);
+      // P3
+      readA(1); issue(0); wait(); mma(1, 1);
+      // P4
+      issue(2); wait(); mma(1, 0);
+    }
+
+    stamp();                                             // [2] main loop done
+    // ---- epilogue.  acc[i][j][e]: row m = m0 + wr*128 + i*16 + r, column n = n0 + wc*64 + j*16 + 4*q4 + e
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int mw = (p.zero_to == -2 ? 0 : tm * 256) + wr * 128, nw = tn * 256 + wc * 64;   // DEBUG zero_to -2: every tile stores to m-tile 0
+    const int ncols = p.N > p.zero_to ? p.N : p.zero_to;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = nw + j * 16 + 4 * q4;
+      const bool real = n < p.N;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && real) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int m = mw + i * 16 + r;
+        const bool live = m < p.M;
+        f32x4 v = acc[i][j] + bv;
+        if (p.pe && real && live) {
+          const f64x4 pv = *reinterpret_cast<const f64x4*>(p.pe + (size_t)(m % p.pe_period) * p.N + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (float)((double)v[e] + pv[e]);
+        }
+        if (p.Res && real && live) v += *reinterpret_cast<const f32x4*>(p.Res + (size_t)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (p.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          v[e] = real ? v[e] : 0.f;
+        }
+        acc[i][j] = v;
+      }
+    }
+    // everything staged so far has landed before the stores join the vmcnt queue (see the header)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp();                                             // [3] epilogue arithmetic done, staged K-tiles landed
+    // accumulator layout -> wave-private LDS slab -> row-contiguous 16-byte stores.  One 16-row block at a time:
+    // fp32: 16 rows x 64 columns x 4 B = 4 KB, 16-byte chunk c of row r2 sits at chunk c ^ r2; a store instruction writes
+    // 4 rows x 256 B.  bf16: 16 rows x 128 B, 8-byte unit u of row r2 at unit u ^ ((r2 & 7) << 1); 8 rows x 128 B per store.
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (p.zero_to == -1) break;   // DEBUG: no stores
+      if (p.C) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(slab + r * 256 + (((j * 4 + q4) ^ r) << 4)) = acc[i][j];
+        const int c = lane & 15, n = nw + c * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r2 = k * 4 + (lane >> 4), m = mw + i * 16 + r2;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(slab + r2 * 256 + ((c ^ r2) << 4));
+          if (m < p.M && n < ncols) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+        }
+      }
+      if (p.Cb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (__bf16)acc[i][j][e];
+          *reinterpret_cast<bf16x4*>(slab + r * 128 + (((j * 4 + q4) ^ ((r & 7) << 1)) << 3)) = o;
+        }
+        const int c = lane & 7, n = nw + c * 8;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int r2 = k * 8 + (lane >> 3), m = mw + i * 16 + r2;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r2 * 128 + (((2 * c) ^ ((r2 & 7) << 1)) << 3));
+          if (m < p.M && n < ncols) *reinterpret_cast<u32x4*>(p.Cb + (size_t)m * p.ldcb + n) = v;
+        }
+      }
+    }
+    stamp();                                             // [4] stores issued
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();                    // balances the stagger barrier of waves 4-7
+}
+
+static int g8_num_cus = 0;
+
+int launch_gemm8(const GemmBigArgs& a, int cfg, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G8_SMEM));
+    attr_set = true;
+  }
+  if (g8_num_cus == 0) {
+    int dev = 0, n = 0;
+    PT_HIP(hipGetDevice(&dev));
+    PT_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    g8_num_cus = n > 0 ? n : 256;
+  }
+  const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256, ntiles = tiles_m * tiles_n;
+  const int grid = ntiles < g8_num_cus ? ntiles : g8_num_cus;
+  static int stagger_us = -1;
+  if (stagger_us < 0) { const char* e = getenv("PT_GEMM_STAGGER"); stagger_us = e ? atoi(e) : 0; }
+  GemmBigArgs b = a;
+  b.stagger = ntiles > grid ? stagger_us * 100 : 0;
+  void* tok = nullptr;
+  if (prof_is_on()) prof_record_begin(s, a.flops > 0 ? a.flops : 2.0 * a.M * a.N * a.K, cfg, &tok);
+  PT_LAUNCH(gemm8_kernel, dim3(grid), dim3(512), G8_SMEM, s, b, tiles_n, ntiles);
+  if (tok) prof_record_end(s, tok);
+  return 0;
+}
+
+}  // namespace pt

@@ -425,6 +425,22 @@ static int row_cfg() {
   return v;
 }
 
+int launch_gemm8(const GemmBigArgs& a, int cfg, hipStream_t s);
+int launch_gemm_row(const GemmBigArgs& a, hipStream_t s);
+// PT_GEMM_ROW: 1 (default) = N = 512 Linears go to the phase-pipelined row kernel (gemm_bf16_row.hip), 0 = two-stage kernel here
+static int gemm_row_mode() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PT_GEMM_ROW"); v = e ? atoi(e) : 1; }
+  return v;
+}
+// PT_GEMM8: 0 = keep the two-stage kernel for the 256 x 256 tile, 1 (default) = phase-pipelined kernel (gemm_bf16_8ph.hip)
+// for EPI_STD with N != 512, 2 = also for N == 512.
+static int gemm8_mode() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PT_GEMM8"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
 int launch_gemm_big(const GemmBigArgs& a, hipStream_t s) {
   PT_CHECK(a.M > 0 && a.N > 0, "gemm_big: empty problem M=%d N=%d", a.M, a.N);
   PT_CHECK(a.K % 64 == 0 && a.K > 0, "gemm_big: K=%d must be a positive multiple of 64", a.K);
@@ -433,6 +449,7 @@ int launch_gemm_big(const GemmBigArgs& a, hipStream_t s) {
   PT_CHECK(a.N % 8 == 0, "gemm_big: N=%d must be a multiple of 8", a.N);
   PT_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm_big: A and W must be 16-byte aligned");
   PT_CHECK((double)a.M * a.lda * 2 < 4.0e9 && (double)a.Npad * a.K * 2 < 4.0e9, "gemm_big: operand larger than 4 GB");
+  const bool row_ok = gemm_row_mode() >= 1 && a.N == 512 && a.Npad == 512 && a.K >= 64 && a.stamps == nullptr;
   if (a.epi == EPI_STD) {
     PT_CHECK(a.C || a.Cb, "gemm_big: no output");
     PT_CHECK((!a.C || (a.ldc >= a.N && a.ldc % 4 == 0 && ((uintptr_t)a.C & 15) == 0)) &&
@@ -442,6 +459,15 @@ int launch_gemm_big(const GemmBigArgs& a, hipStream_t s) {
              "gemm_big: zero_to=%d must be a multiple of 8 within the output rows", a.zero_to);
     PT_CHECK(!a.Res || (a.ldr % 4 == 0 && ((uintptr_t)a.Res & 15) == 0), "gemm_big: residual must be 16-byte aligned rows");
     PT_CHECK(!a.pe || (a.pe_period > 0 && ((uintptr_t)a.pe & 31) == 0), "gemm_big: pe table needs a period and 32-byte alignment");
+    if (row_ok && !a.pe && !a.Res && a.zero_to == 0) return launch_gemm_row(a, s);
+    if (a.K >= 128 && ((a.N != 512 && gemm8_mode() >= 1) || gemm8_mode() >= 2)) {
+      static int dbg = -9;
+      if (dbg == -9) { const char* e = getenv("PT_GEMM8_DBG"); dbg = e ? atoi(e) : 0; }
+      if (dbg == 0) return launch_gemm8(a, 6, s);
+      GemmBigArgs b = a;
+      b.zero_to = -dbg;
+      return launch_gemm8(b, 6, s);
+    }
     if (a.N == 512) return row_cfg() == 0 ? launch_big<128, 512, 2, 4, 64, EPI_STD, 1>(a, 7, s) : launch_big<64, 512, 1, 4, 32, EPI_STD, 2>(a, 7, s);
     return launch_big<256, 256, 2, 4, 64, EPI_STD, 1>(a, 6, s);
   }
@@ -453,10 +479,12 @@ int launch_gemm_big(const GemmBigArgs& a, hipStream_t s) {
              "gemm_big: LNMOD epilogue needs the style table and labels");
     PT_CHECK(a.n_label == 1 || (long long)a.n_label * a.rows_per_clip >= a.M, "gemm_big: %d labels x %d rows < M=%d",
              a.n_label, a.rows_per_clip, a.M);
+    if (row_ok) return launch_gemm_row(a, s);
     return row_cfg() == 0 ? launch_big<128, 512, 2, 4, 64, EPI_LNMOD, 1>(a, 7, s) : launch_big<64, 512, 1, 4, 32, EPI_LNMOD, 2>(a, 7, s);
   }
   PT_CHECK(a.epi == EPI_ADDLN && a.X && a.gamma && a.beta && ((uintptr_t)a.X & 15) == 0,
            "gemm_big: ADDLN epilogue needs gamma, beta and the residual stream X");
+  if (row_ok) return launch_gemm_row(a, s);
   return row_cfg() == 0 ? launch_big<128, 512, 2, 4, 64, EPI_ADDLN, 1>(a, 7, s) : launch_big<64, 512, 1, 4, 32, EPI_ADDLN, 2>(a, 7, s);
 }
 

@@ -1,0 +1,386 @@
+// Row-complete bf16 GEMM for every d_model = 512 Linear of the transformers: C[M,512] = A[M,K] . W[512,K]^T with the
+// LayerNorm that follows the Linear fused into the epilogue (a workgroup owns whole rows).  Same phase-pipelined
+// structure as gemm_bf16_8ph.hip, re-shaped for N = 512:
+//
+//   tile BM x 512, BM = 16*MT (MT = 8 or 10: 128 or 160 rows, chosen per launch so that the tile count fills whole rounds
+//   of the 256 CUs: 75,776 rows are 592 tiles of 128 = 3 rounds, but 474 tiles of 160 = 2 rounds);
+//   8 waves as 1 (M) x 8 (N): wave wn owns columns [64 wn, 64 wn + 64) of ALL BM rows = MT x 4 accumulators of
+//   v_mfma_f32_16x16x32_bf16 (operands swapped: a lane owns one row and 4 consecutive columns per accumulator);
+//   BK = 32 (one MFMA k-step), three LDS stages of [A: BM rows | B-lo: 256 rows | B-hi: 256 rows] x 64 B filled by LDS-DMA;
+//   B-lo / B-hi = the W rows of every wave's column half nh = 0 / 1.
+// A K-tile is two phases, each [ds_reads | DMA issue | counted vmcnt] s_barrier [MT x 2 MFMAs] s_barrier:
+//   P1 reads A + B-lo, issues B-lo and A of K-tile t+2, MFMAs column half 0;  P2 reads B-hi, issues B-hi of t+2, half 1.
+// Waves 4-7 run one barrier behind waves 0-3 (SIMD partners alternate read/DMA and MFMA segments).  A stage is
+// re-filled two phases after its last read, retired by the counted wait three phases after its issue and read four
+// phases after its issue.  The K-tile stream runs across tiles (persistent workgroups).
+// LDS rows are 64 B: 16-byte chunk c of row r sits at chunk c ^ g[(r >> 2) & 3], g = {0,2,3,1} (source-side swizzle,
+// conflict-free for the four 16-lane groups of a ds_read_b128).
+//
+// Epilogues (pt_common.h): EPI_STD (bias / ReLU), EPI_LNMOD, EPI_ADDLN.  No LDS slabs: fp32 rows leave as 16 rows x 64 B
+// per store instruction straight from the accumulators; bf16 rows are paired across adjacent accumulators with
+// v_permlane16_swap so that a lane stores 16 B and an instruction again covers 16 rows x 64 B.
+#include <cstdlib>
+
+#include "pt_common.h"
+
+namespace pt {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+void prof_record_begin(hipStream_t s, double flops, int cfg, void** tok);
+void prof_record_end(hipStream_t s, void* tok);
+bool prof_is_on();
+
+constexpr int GR_AMAX = 10 * 1024;                 // A image of the largest tile (160 rows x 64 B)
+constexpr int GR_STAGE = GR_AMAX + 32768;          // [A | B-lo | B-hi]
+constexpr int GR_RED = 3 * GR_STAGE;               // LayerNorm partial sums: [2][8 waves][160 rows] floats
+constexpr int GR_SMEM = GR_RED + 2 * 8 * 160 * 4;
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+template <int MT, int EPI>
+__global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, const int ntiles) {
+  constexpr int BM = 16 * MT;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int G = gridDim.x;
+  const int tile0 = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                         // stagger half: 0 = waves 0-3, 1 = waves 4-7
+  const int r = lane & 15, q4 = lane >> 4;
+  const int nt = p.K >> 5;
+  const bool extra = MT > 8 && wave + 8 < MT;        // this wave issues a second A instruction per K-tile
+
+  // ---- DMA streams.  One wave-instruction = 16 image rows x 64 B; lane -> row (lane >> 2), LDS chunk (lane & 3).
+  auto gsw = [](int k) { return (0x78 >> (2 * k)) & 3; };   // 0x78 = 01 11 10 00b -> g[0]=0, g[1]=2, g[2]=3, g[3]=1
+  unsigned soffA[2], soffL[2], soffH[2];
+  auto set_srcA = [&](int tl) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int lr = (wave + 8 * i) * 16 + (lane >> 2);
+      const int g = (lane & 3) ^ gsw((lr >> 2) & 3);
+      int m = tl * BM + lr;
+      m = m < p.M ? m : p.M - 1;
+      soffA[i] = ((unsigned)m * (unsigned)p.lda + g * 8) * 2u;
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int lr = (wave + 8 * i) * 16 + (lane >> 2);          // row of the B-lo / B-hi image: wave (lr >> 5), row (lr & 31)
+    const int g = (lane & 3) ^ gsw((lr >> 2) & 3);
+    const int n = (lr >> 5) * 64 + (lr & 31);
+    soffL[i] = ((unsigned)n * (unsigned)p.K + g * 8) * 2u;
+    soffH[i] = ((unsigned)(n + 32) * (unsigned)p.K + g * 8) * 2u;
+  }
+  // cursors: 0 = A + B-lo (issued together in P1), 1 = B-hi (P2)
+  int c_tile[2], c_kt[2], c_buf[2];
+  bool draining = false;
+  auto advance = [&](int c) {
+    c_buf[c] = c_buf[c] == 2 ? 0 : c_buf[c] + 1;
+    if (++c_kt[c] == nt) {
+      c_kt[c] = 0;
+      c_tile[c] += G;
+      if (c == 0 && c_tile[c] < ntiles) set_srcA(c_tile[c]);
+    }
+  };
+  auto issue_p1 = [&]() {
+    if (c_tile[0] >= ntiles) {
+      draining = true;
+      return;
+    }
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.W) + (size_t)c_kt[0] * 64;
+    const unsigned char* ab = reinterpret_cast<const unsigned char*>(p.A) + (size_t)c_kt[0] * 64;
+    unsigned char* st = smem + c_buf[0] * GR_STAGE;
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(wb + soffL[0]), (lds_ptr_t)(st + GR_AMAX + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(wb + soffL[1]), (lds_ptr_t)(st + GR_AMAX + (wave + 8) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(ab + soffA[0]), (lds_ptr_t)(st + wave * 1024), 16, 0, 0);
+    if (extra) __builtin_amdgcn_global_load_lds((glb_ptr_t)(ab + soffA[1]), (lds_ptr_t)(st + (wave + 8) * 1024), 16, 0, 0);
+    advance(0);
+  };
+  auto issue_p2 = [&]() {
+    if (c_tile[1] >= ntiles) {
+      draining = true;
+      return;
+    }
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.W) + (size_t)c_kt[1] * 64;
+    unsigned char* st = smem + c_buf[1] * GR_STAGE + GR_AMAX + 16384;
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(wb + soffH[0]), (lds_ptr_t)(st + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(wb + soffH[1]), (lds_ptr_t)(st + (wave + 8) * 1024), 16, 0, 0);
+    advance(1);
+  };
+  c_tile[0] = c_tile[1] = tile0;
+  c_kt[0] = c_kt[1] = 0;
+  c_buf[0] = c_buf[1] = 0;
+  set_srcA(tile0);
+  issue_p1(); issue_p2(); issue_p1(); issue_p2();                // K-tiles 0 and 1
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();                    // waves 4-7 run one barrier behind
+
+  const int foff = r * 64 + ((q4 ^ gsw((r >> 2) & 3)) << 4);     // fragment read offset inside a 16-row block
+  const int bro = wave * 32 * 64;                                // this wave's rows of the B-lo / B-hi image
+
+  f32x4 acc[MT][4];
+  bf16x8 af[MT], bfr[2];
+  int cbuf = 0;
+  float* red = reinterpret_cast<float*>(smem + GR_RED);
+
+  int stamp_i = 0;
+  auto stamp = [&]() {
+    if (p.stamps && tid == 0 && stamp_i < 64 && blockIdx.x < 256) p.stamps[blockIdx.x * 64 + stamp_i++] = __builtin_amdgcn_s_memrealtime();
+  };
+
+  // keeps one 16-row block's values in place: without it the compiler hoists every epilogue load above the arithmetic
+  // of all blocks and spills hundreds of registers
+#define PT_PIN_BLOCK(i)                                                   \
+  asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3])::"memory")
+  for (int tile = tile0; tile < ntiles; tile += G) {
+    stamp();                                                     // [0]
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < nt; ++t) {
+      const unsigned char* sb = smem + cbuf * GR_STAGE;
+      cbuf = cbuf == 2 ? 0 : cbuf + 1;
+      auto mma = [&](int nh) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            acc[i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][nh * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+      };
+      // P1
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + GR_AMAX + bro + j * 1024 + foff);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + i * 1024 + foff);
+      issue_p1();
+      if (t >= 2) {                                              // retires B-hi of this K-tile's successor (issued 3 phases ago)
+        if (draining) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (extra) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      }
+      if (t == 2) stamp();                                       // [1]
+      mma(0);
+      // P2
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + GR_AMAX + 16384 + bro + j * 1024 + foff);
+      issue_p2();
+      if (t >= 1) {                                              // retires A + B-lo of K-tile t+1 (issued 3 phases ago)
+        if (draining) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (extra) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      }
+      mma(1);
+    }
+    stamp();                                                     // [2] main loop done
+
+    // ---- epilogue.  acc[i][j][e]: row m = tile*BM + i*16 + er, column n = wave*64 + j*16 + 4*eq + e
+    // (lane coordinates are laundered through an empty asm so that the epilogue's address arithmetic is not hoisted out
+    // of the tile loop, where it would cost the main loop its registers)
+    int er = r, eq = q4;
+    asm volatile("" : "+v"(er), "+v"(eq));
+    const int m_base = tile * BM, n_base = wave * 64 + 4 * eq;
+    if (p.bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n_base + j * 16);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i][j] += bv;
+      }
+    }
+    if constexpr (EPI == EPI_ADDLN) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = m_base + i * 16 + er;
+        if (m < p.M) {
+          f32x4 xv[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xv[j] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * 512 + n_base + j * 16);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] += xv[j];
+        }
+        PT_PIN_BLOCK(i);
+      }
+    }
+    // one 16-row block: fp32 rows straight from the accumulators (16 rows x 64 B per instruction); bf16: accumulators j
+    // and j+1 exchange 16-lane rows (v_permlane16_swap), afterwards a lane holds 8 consecutive bf16 columns
+    // (column 16*(j + (eq & 1)) + 8*(eq >> 1) of the wave's 64)
+    float* outf = EPI == EPI_ADDLN ? p.X : (EPI == EPI_STD ? p.C : nullptr);
+    const int ldf = EPI == EPI_ADDLN ? 512 : p.ldc;
+    auto store_block = [&](int i) {
+      const int m = m_base + i * 16 + er;
+      const bool live = m < p.M;
+      if (outf && live) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(outf + (size_t)m * ldf + n_base + j * 16) = acc[i][j];
+      }
+      if (p.Cb) {
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          const unsigned x0 = pack_bf16(acc[i][j][0], acc[i][j][1]), x1 = pack_bf16(acc[i][j][2], acc[i][j][3]);
+          const unsigned y0 = pack_bf16(acc[i][j + 1][0], acc[i][j + 1][1]), y1 = pack_bf16(acc[i][j + 1][2], acc[i][j + 1][3]);
+          const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+          const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+          const int n = wave * 64 + 16 * (j + (eq & 1)) + 8 * (eq >> 1);
+          if (live) *reinterpret_cast<u32x4*>(p.Cb + (size_t)m * p.ldcb + n) = v;
+        }
+      }
+    };
+    if constexpr (EPI != EPI_STD) {
+      // LayerNorm over the 512 columns of a row: lane partials -> 4 lanes of a row (eq) -> 8 waves through LDS.
+      // The partial sums cross the two staggered halves, so waves 0-3 wait for waves 4-7 here and the stagger is
+      // re-established after the epilogue.  Means / variances are re-read from LDS per block (no register arrays).
+      if (grp == 0) __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s += acc[i][j][e];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (eq == 0) red[wave * 160 + i * 16 + er] = s;
+        PT_PIN_BLOCK(i);
+      }
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) tot += red[w * 160 + i * 16 + er];
+        const float mean = tot * (1.f / 512.f);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = acc[i][j][e] - mean;
+            s += d * d;
+          }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (eq == 0) red[8 * 160 + wave * 160 + i * 16 + er] = s;
+        PT_PIN_BLOCK(i);
+      }
+      // every K-tile staged so far has landed before the stores join the in-order vmcnt queue
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      stamp();                                                   // [3] statistics done
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        float tot = 0.f, totq = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          tot += red[w * 160 + i * 16 + er];
+          totq += red[8 * 160 + w * 160 + i * 16 + er];
+        }
+        const float mean = tot * (1.f / 512.f);
+        const float rstd = __builtin_amdgcn_rsqf(totq * (1.f / 512.f) + 1e-5f);
+        const int m = m_base + i * 16 + er;
+        const float* gp = p.gamma;
+        const float* bp = p.beta;
+        if constexpr (EPI == EPI_LNMOD) {
+          const int mc = m < p.M ? m : p.M - 1;
+          long long lb = p.label[p.n_label == 1 ? 0 : mc / p.rows_per_clip];
+          lb = lb < 0 ? 0 : (lb >= p.n_classes ? p.n_classes - 1 : lb);
+          gp = p.style + (size_t)lb * 1024;
+          bp = gp + 512;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(gp + n_base + j * 16);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(bp + n_base + j * 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float y = (acc[i][j][e] - mean) * rstd * ga[e] + be[e];
+            if (EPI == EPI_LNMOD) y = y * __builtin_amdgcn_rcpf(1.f + __expf(-y));
+            acc[i][j][e] = y;
+          }
+        }
+        store_block(i);
+        PT_PIN_BLOCK(i);
+      }
+    } else {
+      if (p.relu) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = acc[i][j][e] > 0.f ? acc[i][j][e] : 0.f;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp();                                                   // [3]
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        store_block(i);
+        PT_PIN_BLOCK(i);
+      }
+    }
+    stamp();                                                     // [4] stores issued
+    if constexpr (EPI != EPI_STD) {
+      if (grp == 1) __builtin_amdgcn_s_barrier();                // waves 4-7 fall one barrier behind again
+    }
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();                    // balances the stagger barrier of waves 4-7
+}
+
+static int gr_num_cus = 0;
+
+template <int MT, int EPI>
+static int launch_row(const GemmBigArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_row_kernel<MT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, GR_SMEM));
+    attr_set = true;
+  }
+  const int ntiles = (a.M + 16 * MT - 1) / (16 * MT);
+  const int grid = ntiles < gr_num_cus ? ntiles : gr_num_cus;
+  void* tok = nullptr;
+  if (prof_is_on()) prof_record_begin(s, a.flops > 0 ? a.flops : 2.0 * a.M * a.N * a.K, 7, &tok);
+  PT_LAUNCH((gemm_row_kernel<MT, EPI>), dim3(grid), dim3(512), GR_SMEM, s, a, ntiles);
+  if (tok) prof_record_end(s, tok);
+  return 0;
+}
+
+// Tile height: the one whose tile count wastes less of the last round of the persistent grid.
+int launch_gemm_row(const GemmBigArgs& a, hipStream_t s) {
+  if (gr_num_cus == 0) {
+    int dev = 0, n = 0;
+    PT_HIP(hipGetDevice(&dev));
+    PT_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    gr_num_cus = n > 0 ? n : 256;
+  }
+  static int force_mt = -1;
+  if (force_mt < 0) { const char* e = getenv("PT_GEMM_ROW_MT"); force_mt = e ? atoi(e) : 0; }
+  auto cost = [&](int bm) {
+    const long tiles = (a.M + bm - 1) / bm;
+    return ((tiles + gr_num_cus - 1) / gr_num_cus) * (long)bm;
+  };
+  const bool mt10 = force_mt ? force_mt == 10 : cost(160) <= cost(128);   // ties: the taller tile re-reads W less often
+  if (a.epi == EPI_STD) return mt10 ? launch_row<10, EPI_STD>(a, s) : launch_row<8, EPI_STD>(a, s);
+  if (a.epi == EPI_LNMOD) return mt10 ? launch_row<10, EPI_LNMOD>(a, s) : launch_row<8, EPI_LNMOD>(a, s);
+  return mt10 ? launch_row<10, EPI_ADDLN>(a, s) : launch_row<8, EPI_ADDLN>(a, s);
+}
+
+}  // namespace pt

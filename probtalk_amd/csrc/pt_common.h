@@ -116,6 +116,7 @@ struct GemmBigArgs {
   const float* gamma; const float* beta;
   const float* style; const int64_t* label; int n_label, rows_per_clip, n_classes;
   float* X;
+  int stagger;                        // start-time spread of the workgroups in 100 MHz ticks (0 = none), see launch_gemm8
   unsigned long long* stamps;         // debug: per-workgroup phase timestamps (100 MHz), 64 per workgroup; normally null
   double flops;
 };
