@@ -449,7 +449,7 @@ int launch_gemm_big(const GemmBigArgs& a, hipStream_t s) {
   PT_CHECK(a.N % 8 == 0, "gemm_big: N=%d must be a multiple of 8", a.N);
   PT_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm_big: A and W must be 16-byte aligned");
   PT_CHECK((double)a.M * a.lda * 2 < 4.0e9 && (double)a.Npad * a.K * 2 < 4.0e9, "gemm_big: operand larger than 4 GB");
-  const bool row_ok = gemm_row_mode() >= 1 && a.N == 512 && a.Npad == 512 && a.K >= 64 && a.stamps == nullptr;
+  const bool row_ok = gemm_row_mode() >= 1 && a.N == 512 && a.Npad == 512 && a.K >= 64;
   if (a.epi == EPI_STD) {
     PT_CHECK(a.C || a.Cb, "gemm_big: no output");
     PT_CHECK((!a.C || (a.ldc >= a.N && a.ldc % 4 == 0 && ((uintptr_t)a.C & 15) == 0)) &&

@@ -9,7 +9,7 @@
 //   BK = 32 (one MFMA k-step), three LDS stages of [A: BM rows | B-lo: 256 rows | B-hi: 256 rows] x 64 B filled by LDS-DMA;
 //   B-lo / B-hi = the W rows of every wave's column half nh = 0 / 1.
 // A K-tile is two phases, each [ds_reads | DMA issue | counted vmcnt] s_barrier [MT x 2 MFMAs] s_barrier:
-//   P1 reads A + B-lo, issues B-lo and A of K-tile t+2, MFMAs column half 0;  P2 reads B-hi, issues B-hi of t+2, half 1.
+//   P1 reads A + B-lo, issues B-lo of K-tile t+2, MFMAs column half 0;  P2 reads B-hi, issues A then B-hi of t+2, half 1.
 // Waves 4-7 run one barrier behind waves 0-3 (SIMD partners alternate read/DMA and MFMA segments).  A stage is
 // re-filled two phases after its last read, retired by the counted wait three phases after its issue and read four
 // phases after its issue.  The K-tile stream runs across tiles (persistent workgroups).
@@ -40,7 +40,9 @@ bool prof_is_on();
 constexpr int GR_AMAX = 10 * 1024;                 // A image of the largest tile (160 rows x 64 B)
 constexpr int GR_STAGE = GR_AMAX + 32768;          // [A | B-lo | B-hi]
 constexpr int GR_RED = 3 * GR_STAGE;               // LayerNorm partial sums: [2][8 waves][160 rows] floats
-constexpr int GR_SMEM = GR_RED + 2 * 8 * 160 * 4;
+constexpr int GR_TAB = GR_RED + 2 * 8 * 160 * 4;   // LayerNorm affine tables: [classes][gamma' 512 | beta' 512] floats, 4 classes at most
+constexpr int GR_TAB_CLASSES = 4;
+constexpr int GR_SMEM = GR_TAB + GR_TAB_CLASSES * 4096;
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   bf16x2 v = {(__bf16)a, (__bf16)b};
@@ -58,6 +60,12 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
   const int grp = wave >> 2;                         // stagger half: 0 = waves 0-3, 1 = waves 4-7
   const int r = lane & 15, q4 = lane >> 4;
   const int nt = p.K >> 5;
+  if (p.stagger > 0 && (blockIdx.x & 8)) {
+    // half of the workgroups start late: left alone, all CUs run their main loops together (HBM idle) and then
+    // their HBM-bound epilogues together (matrix cores idle)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(8);
+  }
   const bool extra = MT > 8 && wave + 8 < MT;        // this wave issues a second A instruction per K-tile
 
   // ---- DMA streams.  One wave-instruction = 16 image rows x 64 B; lane -> row (lane >> 2), LDS chunk (lane & 3).
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
     soffL[i] = ((unsigned)n * (unsigned)p.K + g * 8) * 2u;
     soffH[i] = ((unsigned)(n + 32) * (unsigned)p.K + g * 8) * 2u;
   }
-  // cursors: 0 = A + B-lo (issued together in P1), 1 = B-hi (P2)
+  // cursors: 0 = B-lo (issued in P1, beside the 12 fragment reads), 1 = A + B-hi (P2, which reads 2 fragments only)
   int c_tile[2], c_kt[2], c_buf[2];
   bool draining = false;
   auto advance = [&](int c) {
@@ -89,7 +97,7 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
     if (++c_kt[c] == nt) {
       c_kt[c] = 0;
       c_tile[c] += G;
-      if (c == 0 && c_tile[c] < ntiles) set_srcA(c_tile[c]);
+      if (c == 1 && c_tile[c] < ntiles) set_srcA(c_tile[c]);
     }
   };
   auto issue_p1 = [&]() {
@@ -98,12 +106,9 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
       return;
     }
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.W) + (size_t)c_kt[0] * 64;
-    const unsigned char* ab = reinterpret_cast<const unsigned char*>(p.A) + (size_t)c_kt[0] * 64;
     unsigned char* st = smem + c_buf[0] * GR_STAGE;
     __builtin_amdgcn_global_load_lds((glb_ptr_t)(wb + soffL[0]), (lds_ptr_t)(st + GR_AMAX + wave * 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((glb_ptr_t)(wb + soffL[1]), (lds_ptr_t)(st + GR_AMAX + (wave + 8) * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)(ab + soffA[0]), (lds_ptr_t)(st + wave * 1024), 16, 0, 0);
-    if (extra) __builtin_amdgcn_global_load_lds((glb_ptr_t)(ab + soffA[1]), (lds_ptr_t)(st + (wave + 8) * 1024), 16, 0, 0);
     advance(0);
   };
   auto issue_p2 = [&]() {
@@ -112,11 +117,26 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
       return;
     }
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.W) + (size_t)c_kt[1] * 64;
-    unsigned char* st = smem + c_buf[1] * GR_STAGE + GR_AMAX + 16384;
+    const unsigned char* ab = reinterpret_cast<const unsigned char*>(p.A) + (size_t)c_kt[1] * 64;
+    unsigned char* sa = smem + c_buf[1] * GR_STAGE;
+    unsigned char* st = sa + GR_AMAX + 16384;
+    // A first: the P2 wait one K-tile later retires it (it is read in the following P1), B-hi may still be in flight then
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(ab + soffA[0]), (lds_ptr_t)(sa + wave * 1024), 16, 0, 0);
+    if (extra) __builtin_amdgcn_global_load_lds((glb_ptr_t)(ab + soffA[1]), (lds_ptr_t)(sa + (wave + 8) * 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((glb_ptr_t)(wb + soffH[0]), (lds_ptr_t)(st + wave * 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((glb_ptr_t)(wb + soffH[1]), (lds_ptr_t)(st + (wave + 8) * 1024), 16, 0, 0);
     advance(1);
   };
+  // LayerNorm affine tables into LDS (read per 16-row block in the epilogue: from global memory each block paid a
+  // label -> table -> value chain of dependent loads)
+  float* tab = reinterpret_cast<float*>(smem + GR_TAB);
+  if constexpr (EPI == EPI_LNMOD) {
+    for (int k = tid; k < p.n_classes * 256; k += 512)
+      *reinterpret_cast<f32x4*>(tab + 4 * k) = *reinterpret_cast<const f32x4*>(p.style + 4 * k);
+  } else if constexpr (EPI == EPI_ADDLN) {
+    if (tid < 128) *reinterpret_cast<f32x4*>(tab + 4 * tid) = *reinterpret_cast<const f32x4*>(p.gamma + 4 * tid);
+    else if (tid < 256) *reinterpret_cast<f32x4*>(tab + 4 * tid) = *reinterpret_cast<const f32x4*>(p.beta + 4 * (tid - 128));
+  }
   c_tile[0] = c_tile[1] = tile0;
   c_kt[0] = c_kt[1] = 0;
   c_buf[0] = c_buf[1] = 0;
@@ -145,10 +165,25 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
   asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3])::"memory")
   for (int tile = tile0; tile < ntiles; tile += G) {
     stamp();                                                     // [0]
+    // accumulators start at the bias.  (Starting them at bias + residual row for EPI_ADDLN was measured: the 320 KB of x per
+    // tile then stand in front of the first MFMAs, 142 us against 130 us per launch at 75,776 rows.)
+    {
+      int ir = r, iq = q4;
+      asm volatile("" : "+v"(ir), "+v"(iq));
+      const int nb = wave * 64 + 4 * iq;
+      f32x4 bv[4];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+      for (int j = 0; j < 4; ++j) bv[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < MT; ++i) {
+        const int m = tile * BM + i * 16 + ir;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = bv[j];
+        }
+        (void)m;
+      }
+    }
 
     for (int t = 0; t < nt; ++t) {
       const unsigned char* sb = smem + cbuf * GR_STAGE;
@@ -172,10 +207,10 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
 #pragma unroll
       for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + i * 1024 + foff);
       issue_p1();
-      if (t >= 2) {                                              // retires B-hi of this K-tile's successor (issued 3 phases ago)
+      if (t >= 2) {                                              // retires A and B-hi issued 3 phases ago (read from P2 / next P1 on)
         if (draining) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (extra) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (extra) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // B-lo 2 + (A 2 + B-hi 2) + B-lo 2
+        else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                  // B-lo 2 + (A 1 + B-hi 2) + B-lo 2
       }
       if (t == 2) stamp();                                       // [1]
       mma(0);
@@ -183,10 +218,10 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
 #pragma unroll
       for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + GR_AMAX + 16384 + bro + j * 1024 + foff);
       issue_p2();
-      if (t >= 1) {                                              // retires A + B-lo of K-tile t+1 (issued 3 phases ago)
+      if (t >= 1) {                                              // retires B-lo issued 3 phases ago AND the A issued 2 phases ago
         if (draining) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (extra) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else if (extra) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // B-hi 2 + B-lo 2 + (A 2 + B-hi 2)
+        else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                  // B-hi 2 + B-lo 2 + (A 1 + B-hi 2)
       }
       mma(1);
     }
@@ -198,26 +233,35 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
     int er = r, eq = q4;
     asm volatile("" : "+v"(er), "+v"(eq));
     const int m_base = tile * BM, n_base = wave * 64 + 4 * eq;
-    if (p.bias) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n_base + j * 16);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i][j] += bv;
-      }
-    }
-    if constexpr (EPI == EPI_ADDLN) {
+    int cls[MT];
+    if constexpr (EPI == EPI_LNMOD) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int m = m_base + i * 16 + er;
-        if (m < p.M) {
-          f32x4 xv[4];
+        const int mc = m < p.M ? m : p.M - 1;
+        const long long lb = p.label[p.n_label == 1 ? 0 : mc / p.rows_per_clip];
+        cls[i] = lb < 0 ? 0 : (lb >= p.n_classes ? p.n_classes - 1 : (int)lb);
+      }
+    }
+    (void)cls;
+    if constexpr (EPI == EPI_ADDLN) {
+      // residual rows, two 16-row blocks per round trip (the fragment registers are free here)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) xv[j] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * 512 + n_base + j * 16);
+      for (int i = 0; i < MT; i += 2) {
+        f32x4 xv[2][4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] += xv[j];
+        for (int k = 0; k < 2; ++k) {
+          const int m = m_base + (i + k) * 16 + er;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            xv[k][j] = m < p.M ? *reinterpret_cast<const f32x4*>(p.X + (size_t)m * 512 + n_base + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i + k][j] += xv[k][j];
         PT_PIN_BLOCK(i);
+        PT_PIN_BLOCK(i + 1);
       }
     }
     // one 16-row block: fp32 rows straight from the accumulators (16 rows x 64 B per instruction); bf16: accumulators j
@@ -296,24 +340,18 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
         }
         const float mean = tot * (1.f / 512.f);
         const float rstd = __builtin_amdgcn_rsqf(totq * (1.f / 512.f) + 1e-5f);
-        const int m = m_base + i * 16 + er;
-        const float* gp = p.gamma;
-        const float* bp = p.beta;
-        if constexpr (EPI == EPI_LNMOD) {
-          const int mc = m < p.M ? m : p.M - 1;
-          long long lb = p.label[p.n_label == 1 ? 0 : mc / p.rows_per_clip];
-          lb = lb < 0 ? 0 : (lb >= p.n_classes ? p.n_classes - 1 : lb);
-          gp = p.style + (size_t)lb * 1024;
-          bp = gp + 512;
-        }
+        const float nmr = -mean * rstd;
+        const float* gp = tab + n_base;
+        if constexpr (EPI == EPI_LNMOD) gp += cls[i] * 1024;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const f32x4 ga = *reinterpret_cast<const f32x4*>(gp + n_base + j * 16);
-          const f32x4 be = *reinterpret_cast<const f32x4*>(bp + n_base + j * 16);
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(gp + j * 16);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(gp + 512 + j * 16);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float y = (acc[i][j][e] - mean) * rstd * ga[e] + be[e];
-            if (EPI == EPI_LNMOD) y = y * __builtin_amdgcn_rcpf(1.f + __expf(-y));
+            float y = __builtin_fmaf(__builtin_fmaf(acc[i][j][e], rstd, nmr), ga[e], be[e]);
+            // SiLU = y / (1 + 2^(-y log2 e)) on the raw v_exp_f32 / v_rcp_f32 (2^z overflows to inf -> y * 0 for y << 0)
+            if (EPI == EPI_LNMOD) y = y * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(y * -1.4426950408889634f));
             acc[i][j][e] = y;
           }
         }
@@ -356,9 +394,13 @@ static int launch_row(const GemmBigArgs& a, hipStream_t s) {
   }
   const int ntiles = (a.M + 16 * MT - 1) / (16 * MT);
   const int grid = ntiles < gr_num_cus ? ntiles : gr_num_cus;
+  static int stagger_us = -1;
+  if (stagger_us < 0) { const char* e = getenv("PT_GEMM_STAGGER"); stagger_us = e ? atoi(e) : 0; }
+  GemmBigArgs b = a;
+  b.stagger = (EPI == EPI_ADDLN && ntiles > grid) ? stagger_us * 100 : 0;
   void* tok = nullptr;
   if (prof_is_on()) prof_record_begin(s, a.flops > 0 ? a.flops : 2.0 * a.M * a.N * a.K, 7, &tok);
-  PT_LAUNCH((gemm_row_kernel<MT, EPI>), dim3(grid), dim3(512), GR_SMEM, s, a, ntiles);
+  PT_LAUNCH((gemm_row_kernel<MT, EPI>), dim3(grid), dim3(512), GR_SMEM, s, b, ntiles);
   if (tok) prof_record_end(s, tok);
   return 0;
 }
