@@ -4,7 +4,7 @@
 // 512 threads = 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4 v_mfma_f32_16x16x32_bf16 accumulators.
 // A K-tile (BK = 64) is staged by LDS-DMA (global_load_lds_dwordx4) as FOUR half-tile images of 128 rows x 128 B:
 //   h0 / h1 = the 64-row halves mh = 0 / 1 of every wave's A rows,  h2 / h3 = the 32-column halves nh = 0 / 1 of every
-//   wave's W rows, two K-tile buffers (2 x 4 x 16 KB = 128 KB) + 8 wave-private 4 KB store slabs = 160 KB.
+//   wave's W rows, two K-tile buffers (2 x 4 x 16 KB = 128 KB).
 // A K-tile is four phases of 16 MFMAs, one output quadrant (mh, nh) x K = 64 each:
 //   P1 reads B(nh0) + A(mh0), MFMA (0,0);  P2 reads B(nh1), MFMA (0,1);  P3 reads A(mh1), MFMA (1,1);  P4 MFMA (1,0).
 // Every phase is  [ds_reads | DMA issue of ONE half-tile | counted vmcnt]  s_barrier  [16 MFMAs]  s_barrier, and
@@ -38,8 +38,13 @@ bool prof_is_on();
 
 constexpr int G8_HT = 128 * 128;          // bytes of a half-tile image (128 rows x 64 bf16)
 constexpr int G8_STAGE = 4 * G8_HT;       // one K-tile buffer
-constexpr int G8_SLAB = 4096;             // wave-private store slab
-constexpr int G8_SMEM = 2 * G8_STAGE + 8 * G8_SLAB;
+constexpr int G8_SMEM = 2 * G8_STAGE;
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
 
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const int tiles_n, const int ntiles) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -121,7 +126,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
   f32x4 acc[8][4];
   bf16x8 af[4][2], bfr[2][2][2];
   int cbuf = 0;
-  unsigned char* slab = smem + 2 * G8_STAGE + wave * G8_SLAB;
 
   int stamp_i = 0;
   auto stamp = [&]() {
@@ -129,10 +133,20 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
   };
   for (int tile = tile0; tile < ntiles; tile += G) {
     stamp();                                             // [0] tile start
+    {
+      // accumulators start at the bias (its loads overlap the first K-tile instead of standing in the epilogue)
+      int iq = q4;
+      asm volatile("" : "+v"(iq));
+      const int tn0 = tile - (tile / tiles_n) * tiles_n;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int j = 0; j < 4; ++j) {
+        const int n = tn0 * 256 + wc * 64 + j * 16 + 4 * iq;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 8; ++i) acc[i][j] = bv;
+      }
+    }
 
     for (int t = 0; t < nt; ++t, cbuf ^= 1) {
       const unsigned char* sb = smem + cbuf * G8_STAGE;
@@ -186,71 +200,67 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
 
     stamp();                                             // [2] main loop done
     // ---- epilogue.  acc[i][j][e]: row m = m0 + wr*128 + i*16 + r, column n = n0 + wc*64 + j*16 + 4*q4 + e
+    // (lane coordinates laundered so that the address arithmetic is not hoisted into the main loop's registers)
+    int er = r, eq = q4;
+    asm volatile("" : "+v"(er), "+v"(eq));
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int mw = (p.zero_to == -2 ? 0 : tm * 256) + wr * 128, nw = tn * 256 + wc * 64;   // DEBUG zero_to -2: every tile stores to m-tile 0
     const int ncols = p.N > p.zero_to ? p.N : p.zero_to;
+    if (p.pe || p.Res || p.relu || nw + 64 > p.N) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = nw + j * 16 + 4 * q4;
-      const bool real = n < p.N;
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias && real) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+      for (int j = 0; j < 4; ++j) {
+        const int n = nw + j * 16 + 4 * eq;
+        const bool real = n < p.N;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int m = mw + i * 16 + r;
-        const bool live = m < p.M;
-        f32x4 v = acc[i][j] + bv;
-        if (p.pe && real && live) {
-          const f64x4 pv = *reinterpret_cast<const f64x4*>(p.pe + (size_t)(m % p.pe_period) * p.N + n);
+        for (int i = 0; i < 8; ++i) {
+          const int m = mw + i * 16 + er;
+          const bool live = m < p.M;
+          f32x4 v = acc[i][j];
+          if (p.pe && real && live) {
+            const f64x4 pv = *reinterpret_cast<const f64x4*>(p.pe + (size_t)(m % p.pe_period) * p.N + n);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (float)((double)v[e] + pv[e]);
+            for (int e = 0; e < 4; ++e) v[e] = (float)((double)v[e] + pv[e]);
+          }
+          if (p.Res && real && live) v += *reinterpret_cast<const f32x4*>(p.Res + (size_t)m * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (p.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            v[e] = real ? v[e] : 0.f;
+          }
+          acc[i][j] = v;
         }
-        if (p.Res && real && live) v += *reinterpret_cast<const f32x4*>(p.Res + (size_t)m * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (p.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
-          v[e] = real ? v[e] : 0.f;
-        }
-        acc[i][j] = v;
       }
     }
     // everything staged so far has landed before the stores join the vmcnt queue (see the header)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp();                                             // [3] epilogue arithmetic done, staged K-tiles landed
-    // accumulator layout -> wave-private LDS slab -> row-contiguous 16-byte stores.  One 16-row block at a time:
-    // fp32: 16 rows x 64 columns x 4 B = 4 KB, 16-byte chunk c of row r2 sits at chunk c ^ r2; a store instruction writes
-    // 4 rows x 256 B.  bf16: 16 rows x 128 B, 8-byte unit u of row r2 at unit u ^ ((r2 & 7) << 1); 8 rows x 128 B per store.
+    // fp32 rows leave straight from the accumulators (16 rows x 64 B per instruction); bf16: accumulators j and j+1
+    // exchange 16-lane rows (v_permlane16_swap), then a lane holds 8 consecutive bf16 columns
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (p.zero_to == -1) break;   // DEBUG: no stores
+      const int m = mw + i * 16 + er;
+      const bool live = m < p.M;
       if (p.C) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<f32x4*>(slab + r * 256 + (((j * 4 + q4) ^ r) << 4)) = acc[i][j];
-        const int c = lane & 15, n = nw + c * 4;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int r2 = k * 4 + (lane >> 4), m = mw + i * 16 + r2;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(slab + r2 * 256 + ((c ^ r2) << 4));
-          if (m < p.M && n < ncols) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+        for (int j = 0; j < 4; ++j) {
+          const int n = nw + j * 16 + 4 * eq;
+          if (live && n < ncols) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = acc[i][j];
         }
       }
       if (p.Cb) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (__bf16)acc[i][j][e];
-          *reinterpret_cast<bf16x4*>(slab + r * 128 + (((j * 4 + q4) ^ ((r & 7) << 1)) << 3)) = o;
-        }
-        const int c = lane & 7, n = nw + c * 8;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int r2 = k * 8 + (lane >> 3), m = mw + i * 16 + r2;
-          const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r2 * 128 + (((2 * c) ^ ((r2 & 7) << 1)) << 3));
-          if (m < p.M && n < ncols) *reinterpret_cast<u32x4*>(p.Cb + (size_t)m * p.ldcb + n) = v;
+        for (int j = 0; j < 4; j += 2) {
+          const unsigned x0 = pack_bf16(acc[i][j][0], acc[i][j][1]), x1 = pack_bf16(acc[i][j][2], acc[i][j][3]);
+          const unsigned y0 = pack_bf16(acc[i][j + 1][0], acc[i][j + 1][1]), y1 = pack_bf16(acc[i][j + 1][2], acc[i][j + 1][3]);
+          const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+          const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+          const int n = nw + 16 * (j + (eq & 1)) + 8 * (eq >> 1);
+          if (live && n < ncols) *reinterpret_cast<u32x4*>(p.Cb + (size_t)m * p.ldcb + n) = v;
         }
       }
+      asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3])::"memory");
     }
     stamp();                                             // [4] stores issued
   }
