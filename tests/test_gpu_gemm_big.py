@@ -105,3 +105,70 @@ def test_big_gemm_rejects_bad_geometry():
     rc = L.pt_gemm_bf16(_lib.ptr(A), 96, _lib.ptr(W), None, 64, 512, 96, 512, _lib.ptr(C), 512, None, 0, 0,
                         _lib.stream())
     assert rc != 0 and b"multiple of 64" in L.pt_last_error()
+
+
+# ---- persistent paths: many tiles per workgroup (tile-boundary waits, the K-tile stream running across tiles, the
+# draining tail), checked at the bench's row counts against a float64 reference computed on the GPU, and repeated:
+# the kernels are deterministic, so any difference between runs is a staging race.
+def _ref64(A, W, bias):
+    return A.double() @ W.double().t() + bias.double()
+
+
+@pytest.mark.parametrize("M,N,K", [(75776, 1536, 512), (40000, 2048, 512), (75776, 512, 512), (30001, 512, 2048)])
+def test_persistent_plain_matches_reference_and_repeats(M, N, K):
+    L = _lib.lib()
+    A, W, bias, Np = _mk(M, N, K, 3)
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    ref = _ref64(Ad, Wd[:N], bd[:N])
+    scale = float(ref.abs().max())
+    first = None
+    for rep in range(4):
+        C = torch.empty(M, N, device="cuda")
+        Cb = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        _lib.check(L.pt_gemm_bf16(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, N, K, Np, _lib.ptr(C), N, _lib.ptr(Cb), N, 0,
+                                  _lib.stream()))
+        torch.cuda.synchronize()
+        if first is None:
+            first = (C, Cb)
+            assert float((C.double() - ref).abs().max()) / scale < 2e-6
+            assert float((Cb.double() - ref).abs().max()) / scale < 5e-3
+        else:
+            assert torch.equal(C, first[0]) and torch.equal(Cb, first[1]), f"run {rep} differs from run 0"
+
+
+@pytest.mark.parametrize("M,K", [(75776, 512), (75776, 2048), (153600, 512)])
+def test_persistent_ln_epilogues_match_reference_and_repeat(M, K):
+    L = _lib.lib()
+    A, W, bias, Np = _mk(M, 512, K, 31)
+    g = torch.Generator().manual_seed(6)
+    gamma, beta = 1 + 0.3 * torch.randn(512, generator=g), 0.2 * torch.randn(512, generator=g)
+    style = 0.5 * torch.randn(4, 1024, generator=g)
+    rpc = 148
+    nclip = (M + rpc - 1) // rpc
+    label = torch.randint(0, 4, (nclip,), generator=g)
+    x0 = torch.randn(M, 512, generator=g)
+    fold = torch.cat([gamma * (1 + style[:, :512]), beta * (1 + style[:, :512]) + style[:, 512:]], dim=1).contiguous()
+    Ad, Wd, bd, sd, ld, gd, btd, x0d = (t.cuda() for t in (A, W, bias, fold, label, gamma, beta, x0))
+    v = _ref64(Ad, Wd[:512], bd[:512])
+    lab_row = ld[torch.arange(M, device="cuda") // rpc]
+    y = _ln(v, gd.double(), btd.double()) * (1 + style.cuda()[lab_row, :512].double()) + style.cuda()[lab_row, 512:].double()
+    ref_mod = y * torch.sigmoid(y)
+    ref_add = _ln(x0d.double() + v, gd.double(), btd.double())
+    first = None
+    for rep in range(3):
+        out = torch.empty(M, 512, device="cuda", dtype=torch.bfloat16)
+        _lib.check(L.pt_gemm_bf16_lnmod(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, K, Np, _lib.ptr(sd), _lib.ptr(ld), nclip, rpc, 4,
+                                        _lib.ptr(out), _lib.stream()))
+        xd = x0d.clone()
+        xb = torch.empty(M, 512, device="cuda", dtype=torch.bfloat16)
+        _lib.check(L.pt_gemm_bf16_addln(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, K, Np, _lib.ptr(gd), _lib.ptr(btd), _lib.ptr(xd),
+                                        _lib.ptr(xb), _lib.stream()))
+        torch.cuda.synchronize()
+        if first is None:
+            first = (out, xd, xb)
+            assert float((out.double() - ref_mod).abs().max()) / float(ref_mod.abs().max()) < 5e-3
+            sc = float(ref_add.abs().max())
+            assert float((xd.double() - ref_add).abs().max()) / sc < 5e-6
+            assert float((xb.double() - ref_add).abs().max()) / sc < 5e-3
+        else:
+            assert torch.equal(out, first[0]) and torch.equal(xd, first[1]) and torch.equal(xb, first[2]), f"run {rep} differs"
