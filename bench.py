@@ -198,10 +198,10 @@ def main():
         _lib.check(L.pt_prof_read(ms, fl, ln))
         _lib.check(L.pt_prof_enable(0))
         names = ("f32 128x128", "f32 64x128", "f32 64x64", "bf16 128x128", "bf16 64x128", "bf16 64x64",
-                 "bf16 256x256 lds-dma", "bf16 128x512 lds-dma +LN epilogues")
+                 "bf16 256x256 8-phase lds-dma (gemm8_kernel)", "bf16 160x512 row-complete +LN epilogues (gemm_row_kernel)")
         dom = range(3, 8) if a.dtype == "bf16" else range(0, 3)     # the dominant kernel family of this mode
         peak = PEAK_BF16_MFMA_TFLOPS if a.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-        kname = "pt::gemm_big_kernel + pt::gemm_bf16_kernel (bf16 MFMA 32x32x16 GEMMs of the transformers)" if a.dtype == "bf16" else \
+        kname = "pt::gemm_row_kernel + pt::gemm8_kernel + pt::gemm_bf16_kernel (bf16 MFMA GEMMs of the transformers and conv stacks)" if a.dtype == "bf16" else \
             "pt::gemm_f32_kernel (tap-GEMM, fp32 MFMA 32x32x2)"
         tot_ms, tot_fl, tot_n = sum(ms[i] for i in dom), sum(fl[i] for i in dom), sum(ln[i] for i in dom)
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
@@ -224,7 +224,7 @@ def main():
         if a.dtype == "bf16" and os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pk = json.load(f)["kernels"]
-            fam = {k: v for k, v in pk.items() if "gemm_big_kernel" in k or "gemm_bf16_kernel" in k}
+            fam = {k: v for k, v in pk.items() if any(t in k for t in ("gemm_row_kernel", "gemm8_kernel", "gemm_big_kernel", "gemm_bf16_kernel"))}
             n = sum(v["launches"] for v in fam.values())
             if n:
                 res["roofline"]["traffic"] = sum(v["launches"] * v["hbm_bytes_per_launch"] for v in fam.values()) / n
