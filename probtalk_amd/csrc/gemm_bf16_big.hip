@@ -479,7 +479,7 @@ int launch_gemm_big(const GemmBigArgs& a, hipStream_t s) {
              "gemm_big: LNMOD epilogue needs the style table and labels");
     PT_CHECK(a.n_label == 1 || (long long)a.n_label * a.rows_per_clip >= a.M, "gemm_big: %d labels x %d rows < M=%d",
              a.n_label, a.rows_per_clip, a.M);
-    if (row_ok) return launch_gemm_row(a, s);
+    if (row_ok && a.n_classes <= 4) return launch_gemm_row(a, s);      // the row kernel keeps 4 classes of style tables in LDS
     return row_cfg() == 0 ? launch_big<128, 512, 2, 4, 64, EPI_LNMOD, 1>(a, 7, s) : launch_big<64, 512, 1, 4, 32, EPI_LNMOD, 2>(a, 7, s);
   }
   PT_CHECK(a.epi == EPI_ADDLN && a.X && a.gamma && a.beta && ((uintptr_t)a.X & 15) == 0,

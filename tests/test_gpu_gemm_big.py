@@ -45,16 +45,17 @@ def test_big_gemm_plain(M, N, K, relu):
     assert bool((C[:, N:] == 7.0).all()) and bool((Cb[:, N:] == 7.0).all())            # nothing outside [0, N)
 
 
-@pytest.mark.parametrize("M,K", [(148 * 3, 512), (300 * 2 + 17, 2048)])
-def test_big_gemm_lnmod(M, K):
+@pytest.mark.parametrize("M,K,ncls", [(148 * 3, 512, 4), (300 * 2 + 17, 2048, 4), (148 * 5, 512, 6)])
+def test_big_gemm_lnmod(M, K, ncls):
+    """ncls = 6 takes the two-stage kernel (the phase-pipelined row kernel keeps at most 4 classes of tables in LDS)."""
     L = _lib.lib()
     A, W, bias, Np = _mk(M, 512, K, 11)
     g = torch.Generator().manual_seed(5)
     gamma, beta = 1 + 0.3 * torch.randn(512, generator=g), 0.2 * torch.randn(512, generator=g)
-    style = 0.5 * torch.randn(4, 1024, generator=g)
+    style = 0.5 * torch.randn(ncls, 1024, generator=g)
     rpc = 148
     nclip = (M + rpc - 1) // rpc
-    label = torch.randint(0, 4, (nclip,), generator=g)
+    label = torch.randint(0, ncls, (nclip,), generator=g)
     v = A.double() @ W[:512].double().t() + bias[:512].double()
     lab_row = label[torch.arange(M) // rpc]
     y = _ln(v, gamma.double(), beta.double()) * (1 + style[lab_row, :512].double()) + style[lab_row, 512:].double()
@@ -64,14 +65,14 @@ def test_big_gemm_lnmod(M, K):
     fold = torch.cat([gamma * (1 + style[:, :512]), beta * (1 + style[:, :512]) + style[:, 512:]], dim=1).contiguous()
     Ad, Wd, bd, sd, ld = (t.cuda() for t in (A, W, bias, fold, label))   # keep them alive
     _lib.check(L.pt_gemm_bf16_lnmod(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, K, Np, _lib.ptr(sd), _lib.ptr(ld),
-                                    nclip, rpc, 4, _lib.ptr(out), _lib.stream()))
+                                    nclip, rpc, ncls, _lib.ptr(out), _lib.stream()))
     torch.cuda.synchronize()
     assert float((out.cpu().double() - ref).abs().max()) / float(ref.abs().max()) < 5e-3
     # a single label applies to every row
     out1 = torch.zeros(M, 512, device="cuda", dtype=torch.bfloat16)
     one = torch.tensor([2]).cuda()
     _lib.check(L.pt_gemm_bf16_lnmod(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, K, Np, _lib.ptr(sd), _lib.ptr(one),
-                                    1, rpc, 4, _lib.ptr(out1), _lib.stream()))
+                                    1, rpc, ncls, _lib.ptr(out1), _lib.stream()))
     torch.cuda.synchronize()
     y1 = _ln(v, gamma.double(), beta.double()) * (1 + style[2, :512].double()) + style[2, 512:].double()
     ref1 = y1 * torch.sigmoid(y1)
