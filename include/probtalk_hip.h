@@ -208,6 +208,10 @@ int pt_train_add(const float* a, const float* b, float* out, size_t n, void* str
  * counter = the EMA modules' call count including this call.  rows >= K required. */
 int pt_train_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw,
                     float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, void* stream);
+/* VectorQuantizerEMA.forward train branch (vqvae_modules.py:323-334), the legacy single codebook of s2g_body_vq: the same
+ * EMA update for ONE codebook [K, D] without dead-code re-seeding; any number of latent rows; K may exceed 1024. */
+int pt_train_vq_ema(const float* z, int ldz, const int64_t* idx, int rows, int D, int K, float* counts, float* dw,
+                    float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, void* stream);
 /* vq_teacher.TrainWrapper.get_loss (vq_teacher.py:184-232) on channels-last rows [B*T, ld]: smooth-L1(beta) mean per
  * column range bounds[p]..bounds[p+1] (host arrays, nparts <= 4), velocity L1 mean over the first vel_cols columns;
  * sums (device, nparts+2 floats) = part means | velocity mean | sum_p weights[p]*part_p + velocity; dpred = gradient of

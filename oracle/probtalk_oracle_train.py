@@ -188,3 +188,57 @@ def refiner_train_grads(sd, aud, input_poses, gt_poses, mask, label):
     loss.backward()
     grads = {k: v.grad for k, v in leaf.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None}
     return loss.detach(), parts, grads, pred.detach()
+
+
+# ------------------------------------------------------------------------------------------------ legacy VQ train step
+def vq_ema_train(sd, p, z, commitment_cost=0.25, decay=0.99, eps=1e-5, counter=1):
+    """VectorQuantizerEMA.forward, training branch (vqvae_modules.py:309-348): single codebook, EMA update with Laplace
+    smoothing and NO dead-code re-seeding.  -> (quantized with straight-through gradient (B,D,W), loss, indices, new buffers)."""
+    B, D, W = z.shape
+    x = z.permute(0, 2, 1)
+    flat = x.reshape(-1, D)
+    emb = sd[p + "embeddings"]
+    K = emb.shape[0]
+    ind = torch.argmin(O.code_distances(flat.detach(), emb), dim=1)
+    quantized = F.embedding(ind, emb).reshape(B, W, D)
+    with torch.no_grad():
+        corr = 1 - decay ** counter
+        enc = F.one_hot(ind, K).to(flat.dtype)
+        cs_h = sd[p + "ema_cluster_size.hidden"].clone()
+        cs_h.sub_((cs_h - enc.sum(0)) * (1 - decay))
+        cs = cs_h / corr
+        n = cs.sum()
+        cs = (cs + eps) / (n + K * eps) * n
+        dw_h = sd[p + "ema_dw.hidden"].clone()
+        dw_h.sub_((dw_h - enc.t() @ flat.detach()) * (1 - decay))
+        new = {p + "ema_cluster_size.hidden": cs_h, p + "ema_dw.hidden": dw_h, p + "embeddings": (dw_h / corr) / cs.reshape(-1, 1)}
+    loss = commitment_cost * F.mse_loss(x, quantized.detach())
+    quantized = x + (quantized - x).detach()
+    return quantized.permute(0, 2, 1), loss, ind, new
+
+
+def legacy_vq_losses(pred, gt):
+    """smplx_body_vq.TrainWrapper.get_loss (smplx_body_vq.py:170-190) without the commitment term, pred/gt (B,C,T)."""
+    rec = torch.mean(torch.abs(pred - gt))
+    vel = torch.mean(torch.abs((pred[:, :, 1:] - pred[:, :, :-1]) - (gt[:, :, 1:] - gt[:, :, :-1])))
+    return rec + vel, {"rec_loss": rec, "velocity_loss": vel}
+
+
+def legacy_vq_train_grads(sd, x, counter=1):
+    """One s2g_body_vq step up to the gradients (smplx_body_vq.py:146-163; VQVAE.forward train, vqvae_1d.py:163-173):
+    -> (loss, parts, grads, new buffers incl. BatchNorm running statistics, pred, indices)."""
+    leaf = {k: (v.detach().clone().requires_grad_(True)
+                if v.dtype == torch.float32 and "running" not in k and "embeddings" not in k and "hidden" not in k else v)
+            for k, v in sd.items()}
+    running = {}
+    with bn_train_mode(running):
+        z = O.legacy_encoder(leaf, "encoder.", x)
+        e, e_q_loss, idx, new = vq_ema_train(leaf, "vq_layer.", z, counter=counter)
+        pred = O.legacy_decoder(leaf, "decoder.", e)
+    rec, parts = legacy_vq_losses(pred, x)
+    loss = rec + e_q_loss
+    loss.backward()
+    parts["e_q_loss"] = e_q_loss.detach()
+    grads = {k: v.grad for k, v in leaf.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None}
+    new.update(running)
+    return loss.detach(), parts, grads, new, pred.detach(), idx

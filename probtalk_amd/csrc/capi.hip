@@ -32,7 +32,7 @@ int launch_sumsq(const float* g, size_t n, float* out, hipStream_t s);
 int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* gscale, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t s);
 int launch_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, hipStream_t s);
 int launch_add(const float* a, const float* b, float* out, size_t n, hipStream_t s);
-int launch_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw, float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, hipStream_t s);
+int launch_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw, float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, hipStream_t s, int reseed);
 int launch_vq_losses(const float* pred, int ldp, const float* gt, int ldg, int B, int T, int nparts, const int* bounds, const float* weights, int vel_cols, float beta, float* sums, float* dpred, int lddp, hipStream_t s, const float* nmask, float t_nmask, int l1);
 int launch_sqdiff(const float* a, const float* b, size_t n, float* out, hipStream_t s);
 int launch_commit_bwd(const float* dq, const float* z, const float* q, const float* g, float coef, size_t n, float* dz, hipStream_t s);
@@ -356,7 +356,11 @@ int pt_train_add(const float* a, const float* b, float* out, size_t n, void* str
 }
 int pt_train_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw,
                     float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, void* stream) {
-  return launch_pq_ema(z, ldz, idx, rows, G, D, K, counts, dw, cs_hidden, dw_hidden, emb, decay, eps, counter, (hipStream_t)stream);
+  return launch_pq_ema(z, ldz, idx, rows, G, D, K, counts, dw, cs_hidden, dw_hidden, emb, decay, eps, counter, (hipStream_t)stream, 1);
+}
+int pt_train_vq_ema(const float* z, int ldz, const int64_t* idx, int rows, int D, int K, float* counts, float* dw,
+                    float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, void* stream) {
+  return launch_pq_ema(z, ldz, idx, rows, 1, D, K, counts, dw, cs_hidden, dw_hidden, emb, decay, eps, counter, (hipStream_t)stream, 0);
 }
 int pt_train_vq_losses(const float* pred, int ldp, const float* gt, int ldg, int B, int T, int nparts, const int* bounds,
                        const float* weights, int vel_cols, float beta, float* sums, float* dpred, int lddp, void* stream) {

@@ -1085,40 +1085,45 @@ __global__ __launch_bounds__(1024) void pq_ema_finish_kernel(const float* __rest
                                                              const float* __restrict__ z, int ldz, int D, int K,
                                                              float* __restrict__ cs_hidden, float* __restrict__ dw_hidden,
                                                              float* __restrict__ emb, float one_minus_decay, float eps,
-                                                             float corr) {
+                                                             float corr, int reseed) {
+  // reseed = 1: ProductQuantization (dead codes re-seeded, 529-534); 0: VectorQuantizerEMA (323-334, no re-seeding).
+  // A thread walks codes k, k + blockDim.x, ... (code books larger than one workgroup).
   __shared__ float red[16];
-  const int g = blockIdx.x, k = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float h = 0.f, avg = 0.f;
-  if (k < K) {
-    h = cs_hidden[(size_t)g * K + k];
+  const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float part = 0.f;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float h = cs_hidden[(size_t)g * K + k];
     h -= (h - counts[(size_t)g * K + k]) * one_minus_decay;
-    avg = h / corr;
+    part += h / corr;
   }
-  float part = wsum(avg);
+  part = wsum(part);
   if (lane == 0) red[wave] = part;
   __syncthreads();
   float n = 0.f;
   for (int w = 0; w < (int)(blockDim.x >> 6); ++w) n += red[w];
-  if (k >= K) return;
-  const float sm = (avg + eps) / (n + (float)K * eps) * n;
-  const bool used = sm >= 1.0f;
-  for (int d = 0; d < D; ++d) {
-    const size_t o = ((size_t)g * K + k) * D + d;
-    float hd = dw_hidden[o];
-    hd -= (hd - dw[o]) * one_minus_decay;
-    const float nrm = (hd / corr) / sm;
-    const float rnd = z[(size_t)k * ldz + g * D + d];
-    dw_hidden[o] = used ? hd : rnd;
-    emb[o] = used ? nrm : rnd;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float h = cs_hidden[(size_t)g * K + k];
+    h -= (h - counts[(size_t)g * K + k]) * one_minus_decay;
+    const float avg = h / corr;
+    const float sm = (avg + eps) / (n + (float)K * eps) * n;
+    const bool used = !reseed || sm >= 1.0f;
+    for (int d = 0; d < D; ++d) {
+      const size_t o = ((size_t)g * K + k) * D + d;
+      float hd = dw_hidden[o];
+      hd -= (hd - dw[o]) * one_minus_decay;
+      const float nrm = (hd / corr) / sm;
+      const float rnd = reseed ? z[(size_t)k * ldz + g * D + d] : 0.f;
+      dw_hidden[o] = used ? hd : rnd;
+      emb[o] = used ? nrm : rnd;
+    }
+    cs_hidden[(size_t)g * K + k] = used ? h : 1.0f;
   }
-  cs_hidden[(size_t)g * K + k] = used ? h : 1.0f;
 }
 int launch_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw,
-                  float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, hipStream_t s) {
+                  float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, hipStream_t s, int reseed) {
   PT_CHECK(z && idx && counts && dw && cs_hidden && dw_hidden && emb && G > 0 && D > 0 && K > 0, "pq_ema: bad argument");
-  PT_CHECK(K <= 1024, "pq_ema: %d codes per sub-codebook exceed one workgroup", K);
-  PT_CHECK(rows >= K, "pq_ema: %d latent rows < %d codes (the reference's noisy re-tiling of short batches, "
-                      "vqvae_modules.py:573-577, is not built)", rows, K);
+  PT_CHECK(!reseed || rows >= K, "pq_ema: %d latent rows < %d codes (the reference's noisy re-tiling of short batches, "
+                                 "vqvae_modules.py:573-577, is not built)", rows, K);
   PT_CHECK(counter >= 1 && decay > 0.f && decay < 1.f, "pq_ema: bad decay / counter");
   PT_HIP(hipMemsetAsync(counts, 0, sizeof(float) * G * K, s));
   PT_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)G * K * D, s));
@@ -1127,8 +1132,8 @@ int launch_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, 
             D, K, counts, dw);
   const float omd = (float)(1.0 - (double)decay);
   const float corr = (float)(1.0 - std::pow((double)decay, (double)counter));
-  PT_LAUNCH(pq_ema_finish_kernel, dim3(G), dim3((K + 63) / 64 * 64), 0, s, counts, dw, z, ldz, D, K, cs_hidden, dw_hidden, emb, omd,
-            eps, corr);
+  PT_LAUNCH(pq_ema_finish_kernel, dim3(G), dim3(std::min((K + 63) / 64 * 64, 1024)), 0, s, counts, dw, z, ldz, D, K, cs_hidden,
+            dw_hidden, emb, omd, eps, corr, reseed);
   return 0;
 }
 

@@ -1,8 +1,9 @@
 """`s2g_body_vq` wrapper mirror (nets/smplx_body_vq.py:23-307): the legacy single-codebook VQ-VAE
 (type 'bh' hard-coded at :37; non-composition form)."""
+import numpy as np
 import torch
-import torch.optim as optim
 
+from .. import train_ops, training
 from .base import TrainWrapperBaseClass
 from .modules import VQVAE
 
@@ -26,15 +27,21 @@ class TrainWrapper(TrainWrapperBaseClass):
         else:
             self.g = VQVAE(in_dim, 64, config.Model.code_num, 1024, 2, 512)
         self.discriminator = None
+        # data_utils/lower_body.py:43-63 (c_index / c_index_6d): the 135 body+hand joints kept out of 165
+        fix = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 21, 22, 23, 24, 25, 26, 30, 31, 32, 33, 34, 35]
+        keep = [i for i in range(165) if i not in fix]
+        self.c_index = np.asarray([v for i in keep for v in (2 * i, 2 * i + 1)] if self.convert_to_6d else keep)
         super().__init__(args, config)
 
     def init_optimizer(self):
         lr = self.config.Train.learning_rate.generator_learning_rate
+        # optim.AdamW(betas 0.9/0.999, default weight decay 1e-2) (smplx_body_vq.py:68-86) on the HIP AdamW kernel
+        mk = lambda m: train_ops.AdamW([{'params': m.parameters()}], lr=lr, betas=[0.9, 0.999], weight_decay=1e-2)
         if self.composition:
-            self.g_body_optimizer = optim.AdamW(self.g_body.parameters(), lr=lr, betas=[0.9, 0.999])
-            self.g_hand_optimizer = optim.AdamW(self.g_hand.parameters(), lr=lr, betas=[0.9, 0.999])
+            self.g_body_optimizer = mk(self.g_body)
+            self.g_hand_optimizer = mk(self.g_hand)
         else:
-            self.g_optimizer = optim.AdamW(self.g.parameters(), lr=lr, betas=[0.9, 0.999])
+            self.g_optimizer = mk(self.g)
 
     def state_dict(self):
         if self.composition:
@@ -52,7 +59,50 @@ class TrainWrapper(TrainWrapperBaseClass):
             self.g.load_state_dict(state_dict['g'])
 
     def __call__(self, bat):
-        raise NotImplementedError("s2g_body_vq training step is not built yet")
+        """One training step (smplx_body_vq.py:119-168): body+hand poses through the legacy VQ-VAE in train mode
+        (batch-statistic BatchNorm, single-codebook search, commitment loss + straight-through estimator, EMA codebook
+        update without re-seeding), L1 + velocity L1 + commitment loss (170-190), backward, AdamW; with
+        `composition` one model and one optimizer step per part.  All arithmetic on the HIP training kernels."""
+        self.global_step += 1
+        poses = bat['poses'].to('cuda').to(torch.float32)
+        gt_poses = poses[:, self.c_index, :]
+        loss_dict = {}
+        if self.composition:
+            nb = self.each_dim[1]
+            self.vq_train(gt_poses[:, :nb].contiguous(), 'b', self.g_body, self.g_body_optimizer, loss_dict)
+            self.vq_train(gt_poses[:, nb:].contiguous(), 'h', self.g_hand, self.g_hand_optimizer, loss_dict)
+        else:
+            self.vq_train(gt_poses.contiguous(), 'g', self.g, self.g_optimizer, loss_dict)
+        return None, loss_dict
+
+    def vq_train(self, gt, name, model, optimizer, loss_dict):
+        bs, n, t = gt.shape
+        if next(model.parameters()).device.type != 'cuda':
+            model.cuda()
+        model.train()
+        P = training.tensors_of(model)
+        ql = model.vq_layer
+        gt_rows = train_ops.ncl_to_rows(gt)
+        optimizer.zero_grad()
+        z, e_q_loss, idx, pred, t_out = training.legacy_vq_train_forward(P, ql.embeddings, gt_rows, bs, t, ql.commitment_cost)
+        if t_out != t:
+            raise RuntimeError(f"legacy VQ-VAE training needs T divisible by 4 (got {t}: decoder returns {t_out})")
+        # EMA codebook update (no gradient); the decoder above used the OLD codes, as the reference does (323-334)
+        ql.ema_cluster_size.counter += 1
+        ql.ema_dw.counter += 1
+        train_ops.vq_ema_update(z.detach(), idx, ql.ema_cluster_size.hidden, ql.ema_dw.hidden, ql.embeddings, ql.ema_dw.decay,
+                                ql.epsilon, ql.ema_dw.counter)
+        ql.__dict__['_pt_cb'] = None
+        ones = torch.ones(bs * t, device=gt.device)
+        rec, sums = train_ops.MaskedL1Losses.apply(pred, gt_rows, ones, float(bs * t), bs, t, [0, n], [1.0], n)
+        loss = rec + e_q_loss
+        loss.backward()
+        optimizer.step()
+        model.invalidate()
+        s = sums.tolist()
+        loss_dict[name + 'rec_loss'] = s[0]
+        loss_dict[name + 'velocity_loss'] = s[1]
+        loss_dict[name + 'e_q_loss'] = e_q_loss.item()
 
     def infer_on_audio(self, aud_fn=None, initial_pose=None, norm_stats=None, gt_poses=None, **kwargs):
         """Reconstruct (B,270,T) body+hand poses through the VQ bottleneck (smplx_body_vq.py infer path)."""

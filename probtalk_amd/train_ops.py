@@ -417,6 +417,16 @@ def pq_ema_update(z, idx, cs_hidden, dw_hidden, emb, decay, eps, counter):
                             ptr(dw_hidden), ptr(emb), float(decay), float(eps), int(counter), stream()))
 
 
+def vq_ema_update(z, idx, cs_hidden, dw_hidden, emb, decay, eps, counter):
+    """VectorQuantizerEMA's EMA codebook update (vqvae_modules.py:323-334, no re-seeding) in place on cs_hidden [K],
+    dw_hidden [K,D], emb [K,D]; z rows [B*W, ld] are the encoder output of this step, idx (B*W, 1) its codes."""
+    L = _lib.lib()
+    K, D = emb.shape
+    counts, dw = _empty(1, K), _empty(1, K, D)
+    check(L.pt_train_vq_ema(ptr(z), z.shape[1], ptr(idx), z.shape[0], D, K, ptr(counts), ptr(dw), ptr(cs_hidden), ptr(dw_hidden),
+                            ptr(emb), float(decay), float(eps), int(counter), stream()))
+
+
 class VQLosses(torch.autograd.Function):
     """vq_teacher.get_loss (vq_teacher.py:184-232) without the commitment term: weighted smooth-L1 part losses +
     velocity L1.  Returns (total, sums) with sums = part means | velocity mean | total (device tensor, no gradient)."""

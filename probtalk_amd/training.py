@@ -197,6 +197,28 @@ def vqvae_train_forward(P, codebooks, x_rows, B, Tn, commitment_cost=0.25):
     return z, e_q_loss, idx, pred, Tout
 
 
+# ------------------------------------------------------------------------------------------- legacy VQ-VAE (s2g_body_vq)
+def legacy_vq_train_forward(P, codebook, x_rows, B, Tn, commitment_cost=0.25):
+    """VQVAE.forward in train mode (nets/spg/vqvae_1d.py:66-92,115-144,163-173) without the EMA side effect: encoder with
+    two stride-2 stages, single-codebook nearest-code search + commitment loss + straight-through estimator
+    (VectorQuantizerEMA, vqvae_modules.py:309-348), decoder.  -> (z rows, commitment loss, indices, pred rows, T_out)."""
+    p = "encoder."
+    h, L = _cnr(P, p + "project.", x_rows, B, Tn)
+    h = _res_stack(P, p + "_enc_1.", h, B, L)
+    for i in (1, 2):
+        h, L = _cnr(P, f"{p}_down_{i}.", h, B, L, "down", True)
+        h = _res_stack(P, f"{p}_enc_{i + 1}.", h, B, L)
+    z = T.conv(h, P[p + "pre_vq_conv.weight"], P[p + "pre_vq_conv.bias"], 0, B, L)
+    q, e_q_loss, idx = T.PQQuantizeTrain.apply(z, codebook.unsqueeze(0), commitment_cost)
+    p = "decoder."
+    h = T.conv(q, P[p + "aft_vq_conv.weight"], P[p + "aft_vq_conv.bias"], 0, B, L)
+    h = _res_stack(P, p + "_dec_1.", h, B, L)
+    for i in (2, 3):
+        h, L = _cnr(P, f"{p}_up_{i}.", h, B, L, "up", True)
+        h = _res_stack(P, f"{p}_dec_{i}.", h, B, L)
+    return z, e_q_loss, idx, T.conv(h, P[p + "project.weight"], P[p + "project.bias"], 0, B, L), L
+
+
 # ------------------------------------------------------------------------------------------- refiner
 def rtransformer_train(P, x_rows, cond_rows, label, B, Tn, p_drop, seeds):
     """RTransformer.forward in train mode (RTransformer.py:209-230): x rows (B*T, 384) poses, cond rows (B*T, 800) =

@@ -71,6 +71,15 @@ VQ_TRAIN_GRAD_KEYS = [
     "decoder._dec_4._layers.0.conv.bias", "decoder.project.weight", "decoder.project.bias",
 ]
 
+# gradients stored in tests/golden/legacy_vq_train_b6_t88.npz as grad_<i> (tools/make_golden_legacy_vq_train.py)
+LEGACY_VQ_TRAIN_GRAD_KEYS = [
+    "encoder.project.conv.weight", "encoder.project.norm.weight", "encoder._enc_1._layers.0.conv.weight",
+    "encoder._down_1.residual_layer.weight", "encoder._enc_2.norm.bias", "encoder._down_2.conv.weight",
+    "encoder._enc_3.conv.weight", "encoder.pre_vq_conv.weight", "encoder.pre_vq_conv.bias",
+    "decoder.aft_vq_conv.weight", "decoder._dec_1._layers.1.norm.weight", "decoder._up_2.conv.weight",
+    "decoder._up_3.residual_layer.bias", "decoder._dec_3.conv.weight", "decoder.project.weight", "decoder.project.bias",
+]
+
 # gradients stored in tests/golden/refiner_train_b2_t64.npz as grad_<i> (tools/make_golden_refiner_train.py)
 REFINER_TRAIN_GRAD_KEYS = [
     "input_conv.weight", "input_conv.bias", "audio_conv.weight", "class_embed.weight",
