@@ -132,6 +132,11 @@ int pt_gemm_bf16_addln(const void* A, int lda, const void* W, const float* bias,
  * Q rows b*Nq+i at Q + row*ldq + head*64; K/V rows b*Nk+j likewise; O like Q. */
 int pt_attention_cl(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,
                     int Nq, int Nk, int H, void* stream);
+/* the same core in the bf16 mode: Q/K/V/O are bf16 bit patterns (leading dims in elements, multiples of 8, 16-byte aligned
+ * bases), bf16 MFMA with fp32 softmax statistics and accumulation; K and V of a (clip, head) stay resident in LDS, so
+ * Nk <= 544. */
+int pt_attention_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int B,
+                      int Nq, int Nk, int H, void* stream);
 /* measurement aid (bench.py roofline leg): when enabled every tap-GEMM launch is bracketed by HIP events
  * on its stream; pt_prof_read sums elapsed ms / algorithmic FLOPs / launches per kernel config
  * {fp32 128x128, 64x128, 64x64, bf16 128x128, 64x128, 64x64, bf16 256x256, bf16 128x512} (arrays of 8);

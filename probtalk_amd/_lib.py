@@ -83,6 +83,7 @@ def _proto(lib):
     lib.pt_train_commit_bwd.argtypes = [vp, vp, vp, vp, f, sz, vp, vp]
     lib.pt_debug_set_stamps.argtypes = [vp]
     lib.pt_attention_cl.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, vp]
+    lib.pt_attention_bf16.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name != "pt_version":
@@ -96,7 +97,7 @@ EXPORTS = [
     "pt_pq_quantize_all", "pt_cond_encoder_workspace_bytes", "pt_cond_encoder_forward",
     "pt_predictor_workspace_bytes", "pt_predictor_condition", "pt_predictor_logits", "pt_predictor_sample",
     "pt_refiner_workspace_bytes", "pt_refiner_forward", "pt_interp_blend", "pt_conv1d_cl", "pt_ncl_to_cl",
-    "pt_cl_to_ncl", "pt_pq_search_cl", "pt_pq_gather_cl", "pt_attention_cl", "pt_gemm_bf16", "pt_gemm_bf16_lnmod",
+    "pt_cl_to_ncl", "pt_pq_search_cl", "pt_pq_gather_cl", "pt_attention_cl", "pt_attention_bf16", "pt_gemm_bf16", "pt_gemm_bf16_lnmod",
     "pt_gemm_bf16_addln", "pt_prof_enable",
     "pt_prof_read", "pt_embed_pe", "pt_train_wgrad", "pt_train_colsum", "pt_train_ln_fwd", "pt_train_ln_bwd",
     "pt_train_modsilu_fwd", "pt_train_modsilu_bwd", "pt_train_attention_fwd", "pt_train_attention_bwd",

@@ -134,24 +134,22 @@ __global__ __launch_bounds__(MAXT, WPE) void attention_bf16_kernel(const unsigne
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (c0 + 32 * t) * 128 + koff[s]);
             st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[t], 0, 0, 0);
           }
-          // logits in log2 units (scale * log2 e folded into one multiply); only a partial last tile needs the key mask
+          // raw logits here; scale * log2 e is folded into the exponent's fma below (scale > 0, so the maximum commutes);
+          // only a partial last tile needs the key mask
           if (c0 + 32 * t + 32 <= Nk) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              st[t][r] *= scale;
-              mx = fmaxf(mx, st[t][r]);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int key = c0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h2;
-              st[t][r] = key < Nk ? st[t][r] * scale : -INFINITY;
+              st[t][r] = key < Nk ? st[t][r] : -INFINITY;
               mx = fmaxf(mx, st[t][r]);
             }
           }
         }
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale;
       const float m_new = fmaxf(m_run, mx);
       const float alpha = exp2f(m_run - m_new);
       float psum = 0.f;
@@ -160,7 +158,7 @@ __global__ __launch_bounds__(MAXT, WPE) void attention_bf16_kernel(const unsigne
         if (c0 + 32 * t < Nkp) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            st[t][r] = __builtin_amdgcn_exp2f(st[t][r] - m_new);
+            st[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][r], scale, -m_new));
             psum += st[t][r];
           }
         }

@@ -32,6 +32,7 @@ int launch_sumsq(const float* g, size_t n, float* out, hipStream_t s);
 int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* gscale, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t s);
 int launch_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, hipStream_t s);
 int launch_add(const float* a, const float* b, float* out, size_t n, hipStream_t s);
+int launch_attention_bf16(const unsigned short* Q, int ldq, const unsigned short* K, int ldk, const unsigned short* V, int ldv, unsigned short* O, int ldo, int B, int Nq, int Nk, int H, hipStream_t s);
 int launch_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw, float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, hipStream_t s, int reseed);
 int launch_vq_losses(const float* pred, int ldp, const float* gt, int ldg, int B, int T, int nparts, const int* bounds, const float* weights, int vel_cols, float beta, float* sums, float* dpred, int lddp, hipStream_t s, const float* nmask, float t_nmask, int l1);
 int launch_sqdiff(const float* a, const float* b, size_t n, float* out, hipStream_t s);
@@ -273,6 +274,12 @@ int pt_attention_cl(const float* Q, int ldq, const float* K, int ldk, const floa
                     int Nq, int Nk, int H, void* stream) {
   PT_CHECK(Q && K && V && O, "pt_attention_cl: null argument");
   return launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, Nq, Nk, H, (hipStream_t)stream);
+}
+int pt_attention_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int B,
+                      int Nq, int Nk, int H, void* stream) {
+  PT_CHECK(Q && K && V && O, "pt_attention_bf16: null argument");
+  return launch_attention_bf16((const unsigned short*)Q, ldq, (const unsigned short*)K, ldk, (const unsigned short*)V, ldv,
+                               (unsigned short*)O, ldo, B, Nq, Nk, H, (hipStream_t)stream);
 }
 int pt_pq_gather_cl(const void* idx, int idx_are_int64, const float* codebooks, int rows, int G, int D, int K,
                     float* out, int ldq, void* stream) {
