@@ -86,6 +86,14 @@ int pt_predictor_logits(pt_model* m, const int32_t* ids, const int64_t* label, c
 int pt_predictor_sample(pt_model* m, const int64_t* label, const float* condition, const float* noise_q,
                         const float* noise_g, int steps, int B, int Tq, int32_t* codes_out, float* logits_out, void* ws,
                         size_t ws_bytes, void* stream);
+/* The same loop with both draws generated inside the MaskGIT step kernel (counter-based: splitmix64 of (seed, step,
+ * element) -> 24-bit uniform -> Exp(1) / Gumbel(0,1)): no noise tensors in HBM and no host RNG call per pass (the
+ * reference draws the Gumbel noise on the CPU and copies it each pass, PTransformer.py:697-698).  Same seed, same codes. */
+int pt_predictor_sample_seeded(pt_model* m, const int64_t* label, const float* condition, unsigned long long seed, int steps,
+                               int B, int Tq, int32_t* codes_out, float* logits_out, void* ws, size_t ws_bytes, void* stream);
+/* The noise pt_predictor_sample_seeded uses in pass `step`, written out: noise_q (B,N,V), noise_g (B,N).  Feeding these to
+ * pt_predictor_sample reproduces the seeded codes (test hook; also a stand-alone Exp(1) / Gumbel generator). */
+int pt_maskgit_noise(unsigned long long seed, int step, int B, int N, int V, float* noise_q, float* noise_g, void* stream);
 
 /* ---- refiner ------------------------------------------------------------------------------ */
 size_t pt_refiner_workspace_bytes(const pt_model* m, int B, int T);

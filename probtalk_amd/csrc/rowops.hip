@@ -2,6 +2,7 @@
 // positional encodings, the identity-conditioned "stylization" pre-op (LayerNorm -> (1+scale),shift
 // -> SiLU), post-LN residual, the MaskGIT re-masking step and linear resize + mask blend.
 // d_model is 512 on this path: one 64-lane wave owns one row = 8 floats per lane (2 x dwordx4).
+#include <algorithm>
 #include "transformer.h"
 
 namespace pt {
@@ -178,10 +179,42 @@ int launch_mask_onehot(const float* mask, float* cond, int rows, int ld, int c0,
 //   conf    = log p[sampled] + temp * gumbel, +inf for tokens already known
 //   re-mask every token whose confidence is below the mask_len-th smallest.
 // ---------------------------------------------------------------------------
+// Counter-based noise of the sampler's default mode (no noise tensors in HBM): element idx of stream `stream` under `seed`
+// -> uniform in (0,1) with 24 random bits (splitmix64 finaliser of a Weyl sequence); the categorical draw uses
+// q = -log u ~ Exp(1), the confidence uses g = -log(-log u) ~ Gumbel(0,1).
+__device__ __forceinline__ float mg_uniform(unsigned long long seed, unsigned long long stream, unsigned long long idx) {
+  unsigned long long z = idx * 0x9E3779B97F4A7C15ull + seed * 0xD1B54A32D192ED03ull + stream * 0x8CB92BA72F3D8DD7ull;
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27; z *= 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return ((float)(unsigned)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float mg_exp1(unsigned long long seed, int step, unsigned long long e) {
+  return -logf(mg_uniform(seed, 2ull * step, e));
+}
+__device__ __forceinline__ float mg_gumbel(unsigned long long seed, int step, unsigned long long e) {
+  return -logf(-logf(mg_uniform(seed, 2ull * step + 1, e)));
+}
+// the noise the seeded sampler uses at `step`, written out (tests: injected mode fed with it reproduces the seeded mode)
+__global__ void maskgit_noise_kernel(unsigned long long seed, int step, size_t nq, size_t ng, float* __restrict__ q,
+                                     float* __restrict__ g) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nq; e += (size_t)gridDim.x * blockDim.x) {
+    q[e] = mg_exp1(seed, step, e);
+    if (e < ng) g[e] = mg_gumbel(seed, step, e);
+  }
+}
+int launch_maskgit_noise(unsigned long long seed, int step, int B, int N, int V, float* q, float* g, hipStream_t s) {
+  PT_CHECK(B > 0 && N > 0 && V > 0 && q && g, "maskgit_noise: bad argument");
+  const size_t nq = (size_t)B * N * V, ng = (size_t)B * N;
+  PT_LAUNCH(maskgit_noise_kernel, dim3((unsigned)std::min<size_t>((nq + 255) / 256, 8192)), dim3(256), 0, s, seed, step, nq, ng, q, g);
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void maskgit_step_kernel(const float* __restrict__ logits,
                                                            const float* __restrict__ noise_q,
                                                            const float* __restrict__ noise_g, int* __restrict__ ids,
-                                                           int N, int V, int mask_id, int want_mask, float temp) {
+                                                           int N, int V, int mask_id, int want_mask, float temp,
+                                                           unsigned long long seed, int step) {
   extern __shared__ float sm[];
   float* conf = sm;                                  // [N]
   int* samp = reinterpret_cast<int*>(conf + N);      // [N]
@@ -192,7 +225,7 @@ __global__ __launch_bounds__(256) void maskgit_step_kernel(const float* __restri
   int my_unknown = 0;
   for (int n = wave; n < N; n += 4) {
     const float* lg = logits + ((size_t)b * N + n) * V;
-    const float* q = noise_q + ((size_t)b * N + n) * V;
+    const size_t qbase = ((size_t)b * N + n) * V;            // noise_q == NULL: counter-based noise (seed, step)
     float mx = -INFINITY;
     for (int c = lane; c < V; c += 64) mx = fmaxf(mx, lg[c]);
     mx = wave_max(mx);
@@ -203,7 +236,7 @@ __global__ __launch_bounds__(256) void maskgit_step_kernel(const float* __restri
     int besti = 0x7fffffff;
     for (int c = lane; c < V; c += 64) {
       const float p = expf(lg[c] - mx) / sum;
-      const float r = p / q[c];
+      const float r = p / (noise_q ? noise_q[qbase + c] : mg_exp1(seed, step, qbase + c));
       if (r > best) { best = r; besti = c; bestp = p; }
     }
 #pragma unroll
@@ -216,7 +249,8 @@ __global__ __launch_bounds__(256) void maskgit_step_kernel(const float* __restri
       const int cur = ids[(size_t)b * N + n];
       const bool unk = cur == mask_id;
       samp[n] = unk ? besti : cur;
-      conf[n] = unk ? logf(bestp) + temp * noise_g[(size_t)b * N + n] : INFINITY;
+      const float gn = noise_g ? noise_g[(size_t)b * N + n] : mg_gumbel(seed, step, (size_t)b * N + n);
+      conf[n] = unk ? logf(bestp) + temp * gn : INFINITY;
       my_unknown += unk;
     }
   }
@@ -233,10 +267,11 @@ __global__ __launch_bounds__(256) void maskgit_step_kernel(const float* __restri
   }
 }
 int launch_maskgit_step(const float* logits, const float* noise_q, const float* noise_g, int* ids, int B, int N, int V,
-                        int mask_id, int want_mask, float temp, hipStream_t s) {
+                        int mask_id, int want_mask, float temp, hipStream_t s, unsigned long long seed, int step) {
   PT_CHECK(N > 0 && N <= 8192, "maskgit_step: N=%d out of range", N);
+  PT_CHECK((noise_q == nullptr) == (noise_g == nullptr), "maskgit_step: both noise tensors or neither");
   PT_LAUNCH(maskgit_step_kernel, dim3(B), dim3(256), (size_t)N * 8, s, logits, noise_q, noise_g, ids, N, V,
-                     mask_id, want_mask, temp);
+                     mask_id, want_mask, temp, seed, step);
   return 0;
 }
 

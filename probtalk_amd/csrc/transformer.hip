@@ -25,7 +25,7 @@ int launch_attention_bf16(const unsigned short* Q, int ldq, const unsigned short
                           int ldv, unsigned short* O, int ldo, int B, int Nq, int Nk, int H, hipStream_t s);
 int launch_mask_onehot(const float* mask, float* cond, int rows, int ld, int c0, int zero_to, hipStream_t s);
 int launch_maskgit_step(const float* logits, const float* noise_q, const float* noise_g, int* ids, int B, int N, int V,
-                        int mask_id, int want_mask, float temp, hipStream_t s);
+                        int mask_id, int want_mask, float temp, hipStream_t s, unsigned long long seed, int step);
 int launch_fill_i32(int* p, int v, size_t n, hipStream_t s);
 int launch_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                      int B, int Nq, int Nk, int H, hipStream_t s);
@@ -538,9 +538,10 @@ int predictor_logits(Model& m, const int32_t* ids, const int64_t* label, const f
   return predictor_pass(P, ids, label, pm, tb, B, Tq, bf, logits, s);
 }
 
+// noise_q / noise_g NULL: the MaskGIT step kernel generates both draws itself from (seed, step, element)
 int predictor_sample(Model& m, const int64_t* label, const float* condition, const float* noise_q, const float* noise_g,
                      int steps, int B, int Tq, int32_t* codes_out, float* logits_out, void* ws, size_t ws_bytes,
-                     hipStream_t s) {
+                     hipStream_t s, unsigned long long seed) {
   PT_CHECK(m.finalized && m.pred, "predictor_sample: wrong or unfinalized model");
   PT_CHECK(B > 0 && Tq > 0 && steps > 0, "predictor_sample: empty input B=%d T'=%d steps=%d", B, Tq, steps);
   const Predictor& P = *m.pred;
@@ -566,7 +567,8 @@ int predictor_sample(Model& m, const int64_t* label, const float* condition, con
     const float mask_ratio = (float)cos(ratio * M_PI / 2);
     const int want = (int)floorf((float)N * mask_ratio);
     const float temp = (float)(4.5 * (1.0 - ratio));
-    if (launch_maskgit_step(lt, noise_q + (size_t)t * R * V, noise_g + (size_t)t * R, ids, B, N, V, V, want, temp, s)) return 1;
+    if (launch_maskgit_step(lt, noise_q ? noise_q + (size_t)t * R * V : nullptr, noise_g ? noise_g + (size_t)t * R : nullptr, ids, B,
+                            N, V, V, want, temp, s, seed, t)) return 1;
   }
   PT_HIP(hipMemcpyAsync(codes_out, ids, R * sizeof(int), hipMemcpyDeviceToDevice, s));
   return 0;

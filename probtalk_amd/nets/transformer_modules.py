@@ -156,12 +156,14 @@ class PTransformer(nn.Module):
 
     @torch.no_grad()
     def sample_good(self, label=None, condition=None, input_codes=None, T=10, mode="cosine", noise=None,
-                    return_logits=False):
+                    return_logits=False, seed=None):
         """MaskGIT decoding (PTransformer.py:590-642) -> codes (B,T',G) int32.
 
-        `noise=(q, g)` injects the two random draws (q ~ Exp(1) of shape (T,B,N,num_code) for the
-        categorical sample, g ~ Gumbel(0,1) of shape (T,B,N)); by default they are drawn on the
-        GPU (the reference draws the Gumbel noise on the CPU and copies it each pass)."""
+        `noise=(q, g)` injects the two random draws (q ~ Exp(1) of shape (T,B,N,num_code) for the categorical sample,
+        g ~ Gumbel(0,1) of shape (T,B,N)): the parity mode.  By default both are generated inside the MaskGIT step kernel
+        from a 64-bit seed (`seed=`, else drawn from torch's CPU generator, so torch.manual_seed makes runs repeatable):
+        no noise tensors and no host RNG call per pass (the reference draws the Gumbel noise on the CPU and copies it
+        each pass, PTransformer.py:697-698)."""
         _train_guard(self, "PTransformer.sample_good")
         if mode != "cosine":
             raise NotImplementedError("sample_good is only called with the cosine schedule")
@@ -169,21 +171,22 @@ class PTransformer(nn.Module):
         B, _, Tq = cond.shape
         N = Tq * self.groups
         lab = label.to(device=cond.device, dtype=torch.int64).contiguous()
-        if noise is None:
-            q = torch.empty(T, B, N, self.num_code, device=cond.device).exponential_(1.0)
-            u = torch.rand(T, B, N, device=cond.device).clamp_(1e-20, 1.0 - 1e-7)
-            g = -torch.log(-torch.log(u))
-        else:
-            q, g = (_cuda_f32(t) for t in noise)
-            if tuple(q.shape) != (T, B, N, self.num_code) or tuple(g.shape) != (T, B, N):
-                raise RuntimeError("sample_good: injected noise has the wrong shape")
         h = self._owner()._handle()
         L = _lib.lib()
         codes = torch.empty(B, Tq, self.groups, dtype=torch.int32, device=cond.device)
         logits = torch.empty(T, B, N, self.num_code, device=cond.device) if return_logits else None
         ws = h.workspace(L.pt_predictor_workspace_bytes(h.h, B, Tq * 8))
-        check(L.pt_predictor_sample(h.h, ptr(lab), ptr(cond), ptr(q), ptr(g), T, B, Tq, ptr(codes), ptr(logits),
-                                    ptr(ws), ws.numel(), stream()))
+        if noise is None:
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            check(L.pt_predictor_sample_seeded(h.h, ptr(lab), ptr(cond), int(seed), T, B, Tq, ptr(codes), ptr(logits), ptr(ws),
+                                               ws.numel(), stream()))
+        else:
+            q, g = (_cuda_f32(t) for t in noise)
+            if tuple(q.shape) != (T, B, N, self.num_code) or tuple(g.shape) != (T, B, N):
+                raise RuntimeError("sample_good: injected noise has the wrong shape")
+            check(L.pt_predictor_sample(h.h, ptr(lab), ptr(cond), ptr(q), ptr(g), T, B, Tq, ptr(codes), ptr(logits),
+                                        ptr(ws), ws.numel(), stream()))
         return (codes, logits) if return_logits else codes
 
     def forward(self, x, label, condition, input_codes, epoch_ratio):
