@@ -81,11 +81,12 @@ class GradientReducer:
     of the per-replica gradients and device 0's BatchNorm running statistics are the ones kept.  One process per GPU
     reproduces exactly that with one all-reduce per bucket (RCCL ring over xGMI: per-link bound, so a few large
     messages — 32 MB buckets by default, ~6 for the predictor's 46 M parameters — rather than one per parameter),
-    launched asynchronously so bucket k's copy-out overlaps bucket k+1's transfer, plus a broadcast of rank 0's
-    BatchNorm buffers.  Buckets are filled last-parameter-first, the order backward produces gradients in.
+    launched asynchronously DURING backward (a bucket goes out as soon as its last gradient has been accumulated; buckets
+    are filled last-parameter-first, the order backward produces gradients in), plus a broadcast of rank 0's BatchNorm
+    buffers.
     """
 
-    def __init__(self, params, buffers=(), bucket_bytes=32 << 20):
+    def __init__(self, params, buffers=(), bucket_bytes=32 << 20, overlap=True):
         self.params = [p for p in params if p.requires_grad]
         self.buffers = [b for b in buffers if torch.is_floating_point(b)]
         self.buckets, cur, size = [], [], 0
@@ -98,6 +99,14 @@ class GradientReducer:
         if cur:
             self.buckets.append(cur)
         self._flat = {}
+        # overlap with backward: a bucket is all-reduced as soon as autograd has accumulated the gradient of its last
+        # parameter (post-accumulate-grad hooks), while the earlier layers' gradients are still being computed;
+        # reduce() launches whatever is left (buckets holding a parameter without gradient) and waits for all of them
+        self._bucket_of = {id(p): i for i, bk in enumerate(self.buckets) for p in bk}
+        self._ready = [0] * len(self.buckets)
+        self._pending = {}
+        self.launched_in_backward = 0
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if overlap else []
 
     def _flat_for(self, i, n, like):
         f = self._flat.get(i)
@@ -105,27 +114,43 @@ class GradientReducer:
             f = self._flat[i] = torch.empty(n, dtype=torch.float32, device=like.device)
         return f
 
+    def _launch(self, i):
+        live = [p for p in self.buckets[i] if p.grad is not None]
+        if not live:
+            return
+        flat = self._flat_for(i, sum(p.numel() for p in live), live[0].grad)
+        torch.cat([p.grad.reshape(-1) for p in live], out=flat)
+        self._pending[i] = (dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, live)
+
+    def _on_grad(self, p):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        i = self._bucket_of[id(p)]
+        self._ready[i] += 1
+        if self._ready[i] == len(self.buckets[i]) and i not in self._pending:
+            self._launch(i)
+            self.launched_in_backward += 1
+
     def reduce(self):
         """Call after backward, before clipping / the optimizer step.  Parameters whose gradient is None on this rank
-        (unused on every rank: the graph is the same everywhere) are skipped."""
+        (unused on every rank: the graph is the same everywhere) are skipped.  Buckets completed during backward are
+        already in flight; the rest start here."""
         world = dist.get_world_size()
         if world == 1:
             return
-        pending = []
-        for i, bucket in enumerate(self.buckets):
-            live = [p for p in bucket if p.grad is not None]
-            if not live:
-                continue
-            flat = self._flat_for(i, sum(p.numel() for p in live), live[0].grad)
-            torch.cat([p.grad.reshape(-1) for p in live], out=flat)
-            pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, live))
-        for work, flat, live in pending:
+        for i in range(len(self.buckets)):
+            if i not in self._pending:
+                self._launch(i)
+        for i in sorted(self._pending):
+            work, flat, live = self._pending[i]
             work.wait()
             flat.mul_(1.0 / world)
             off = 0
             for p in live:
                 p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
                 off += p.numel()
+        self._pending = {}
+        self._ready = [0] * len(self.buckets)
 
     def sync_buffers(self):
         """Rank 0's BatchNorm running statistics win, as device 0's do under nn.DataParallel."""

@@ -137,15 +137,17 @@ class TrainWrapper(TrainWrapperBaseClass):
         self.generator_optimizer.zero_grad()
         loss, _ = training.predictor_loss(Pa, Pp, aud, input_poses, mask, id.reshape(-1), state, keep_scores, epoch_ratio,
                                           p_drop=self.train_dropout, seeds=self._seeds, groups=self.config.Model.groups)
+        pa, pp = list(self.AudEnc.parameters()), list(self.Predictor.parameters())
+        multi = torch.distributed.is_available() and torch.distributed.is_initialized() \
+            and torch.distributed.get_world_size() > 1
+        if multi and self.__dict__.get('_reducer') is None:
+            # one process per GPU in place of nn.DataParallel (to_parallel): mean gradient over ranks, rank 0's BN buffers.
+            # Built before backward so that its hooks send each bucket while the earlier layers are still in backward
+            from ..dist import GradientReducer
+            self._reducer = GradientReducer(pa + pp, list(self.AudEnc.buffers()) + list(self.Predictor.buffers()))
         loss.backward()
         max_norm = self.config.Train.max_gradient_norm
-        pa, pp = list(self.AudEnc.parameters()), list(self.Predictor.parameters())
-        if torch.distributed.is_available() and torch.distributed.is_initialized() \
-                and torch.distributed.get_world_size() > 1:
-            # one process per GPU in place of nn.DataParallel (to_parallel): mean gradient over ranks, rank 0's BN buffers
-            if self.__dict__.get('_reducer') is None:
-                from ..dist import GradientReducer
-                self._reducer = GradientReducer(pa + pp, list(self.AudEnc.buffers()) + list(self.Predictor.buffers()))
+        if multi:
             self._reducer.reduce()
             self._reducer.sync_buffers()
         grad_ae, coef_ae = train_ops.clip_grad_norm(pa, max_norm)

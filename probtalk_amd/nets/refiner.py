@@ -122,13 +122,14 @@ class TrainWrapper(TrainWrapperBaseClass):
         self.generator_optimizer.zero_grad()
         loss, sums, _ = training.refiner_loss(P, aud, input_poses, gt_poses, mask, id.reshape(-1), p_drop=self.train_dropout,
                                               seeds=self._seeds)
-        loss.backward()
         params = list(rt.parameters())
-        if torch.distributed.is_available() and torch.distributed.is_initialized() \
-                and torch.distributed.get_world_size() > 1:
-            if self.__dict__.get('_reducer') is None:
-                from ..dist import GradientReducer
-                self._reducer = GradientReducer(params, list(rt.buffers()))
+        multi = torch.distributed.is_available() and torch.distributed.is_initialized() \
+            and torch.distributed.get_world_size() > 1
+        if multi and self.__dict__.get('_reducer') is None:
+            from ..dist import GradientReducer         # before backward: its hooks overlap the all-reduce with it
+            self._reducer = GradientReducer(params, list(rt.buffers()))
+        loss.backward()
+        if multi:
             self._reducer.reduce()
         grad_HF, coef = train_ops.clip_grad_norm(params, self.config.Train.max_gradient_norm)
         self.generator_optimizer.step({p: coef for p in params})

@@ -87,3 +87,44 @@ def _grad_worker(rank, world, port):
 
 def test_gradient_reducer_world2():
     mp.spawn(_grad_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _overlap_worker(rank, world, port):
+    """Gradients produced by a real backward: buckets whose parameters are all used go out from the autograd hooks
+    (before reduce() is called), the bucket holding an unused parameter starts inside reduce(); result = mean over ranks."""
+    from probtalk_amd.dist import GradientReducer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(0)
+        w = [torch.nn.Parameter(torch.randn(64, 64, generator=g)) for _ in range(4)]
+        unused = torch.nn.Parameter(torch.randn(8, generator=g))
+        red = GradientReducer(w[:2] + [unused] + w[2:], bucket_bytes=64 * 64 * 4)
+        assert [len(b) for b in red.buckets] == [1, 1, 2, 1]           # [w3] [w2] [unused, w1] [w0]
+        xs = [torch.randn(16, 64, generator=g) for _ in range(world)]                       # same on every rank
+        for step in range(2):
+            for p in w:
+                p.grad = None
+            h = xs[rank]
+            for p in w:
+                h = torch.tanh(h @ p)
+            h.pow(2).sum().backward()
+            assert red.launched_in_backward == 3 * (step + 1)        # the three complete buckets went out during backward
+            red.reduce()
+            want = []
+            for r in range(world):
+                ps = [p.detach().clone().requires_grad_(True) for p in w]
+                h = xs[r]
+                for p in ps:
+                    h = torch.tanh(h @ p)
+                h.pow(2).sum().backward()
+                want.append([p.grad for p in ps])
+            for i, p in enumerate(w):
+                assert torch.allclose(p.grad, sum(wr[i] for wr in want) / world, atol=1e-5)
+            assert unused.grad is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_reducer_overlaps_backward_world2():
+    mp.spawn(_overlap_worker, args=(2, _free_port()), nprocs=2, join=True)
