@@ -272,7 +272,7 @@ int pt_gemm_bf16_lnmod(const void* A, int lda, const void* W, const float* bias,
 }
 int pt_gemm_bf16_addln(const void* A, int lda, const void* W, const float* bias, int M, int K, int Npad,
                        const float* gamma, const float* beta, float* x, void* x_bf16, void* stream) {
-  PT_CHECK(A && W && x && x_bf16, "pt_gemm_bf16_addln: null argument");
+  PT_CHECK(A && W && x_bf16, "pt_gemm_bf16_addln: null argument");
   GemmBigArgs b;
   memset(&b, 0, sizeof(b));
   b.A = (const unsigned short*)A; b.lda = lda; b.W = (const unsigned short*)W; b.bias = bias;

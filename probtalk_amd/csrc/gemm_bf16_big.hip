@@ -482,9 +482,10 @@ int launch_gemm_big(const GemmBigArgs& a, hipStream_t s) {
     if (row_ok && a.n_classes <= 4) return launch_gemm_row(a, s);      // the row kernel keeps 4 classes of style tables in LDS
     return row_cfg() == 0 ? launch_big<128, 512, 2, 4, 64, EPI_LNMOD, 1>(a, 7, s) : launch_big<64, 512, 1, 4, 32, EPI_LNMOD, 2>(a, 7, s);
   }
-  PT_CHECK(a.epi == EPI_ADDLN && a.X && a.gamma && a.beta && ((uintptr_t)a.X & 15) == 0,
-           "gemm_big: ADDLN epilogue needs gamma, beta and the residual stream X");
-  if (row_ok) return launch_gemm_row(a, s);
+  PT_CHECK(a.epi == EPI_ADDLN && a.gamma && a.beta && ((uintptr_t)a.X & 15) == 0,
+           "gemm_big: ADDLN epilogue needs gamma, beta and a 16-byte aligned residual stream");
+  if (row_ok) return launch_gemm_row(a, s);          // X == nullptr: bf16 residual stream, Cb updated in place
+  PT_CHECK(a.X, "gemm_big: the bf16 residual stream (X == nullptr) needs the row kernel (N = 512, K >= 64, PT_GEMM_ROW on)");
   return row_cfg() == 0 ? launch_big<128, 512, 2, 4, 64, EPI_ADDLN, 1>(a, 7, s) : launch_big<64, 512, 1, 4, 32, EPI_ADDLN, 2>(a, 7, s);
 }
 

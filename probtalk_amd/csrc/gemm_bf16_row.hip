@@ -49,9 +49,13 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-template <int MT, int EPI>
+constexpr int EPI_ADDLN_B = 3;   // EPI_ADDLN with the bf16 residual stream (X == nullptr): its own instantiation
+
+template <int MT, int EPIX>
 __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, const int ntiles) {
   constexpr int BM = 16 * MT;
+  constexpr bool RESB = EPIX == EPI_ADDLN_B;
+  constexpr int EPI = RESB ? EPI_ADDLN : EPIX;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int G = gridDim.x;
   const int tile0 = blockIdx.x;
@@ -245,29 +249,72 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
     }
     (void)cls;
     if constexpr (EPI == EPI_ADDLN) {
-      // residual rows, two 16-row blocks per round trip (the fragment registers are free here)
+      if constexpr (!RESB) {
+        // fp32 residual rows, two 16-row blocks per round trip (the fragment registers are free here)
 #pragma unroll
-      for (int i = 0; i < MT; i += 2) {
-        f32x4 xv[2][4];
+        for (int i = 0; i < MT; i += 2) {
+          f32x4 xv[2][4];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int m = m_base + (i + k) * 16 + er;
+          for (int k = 0; k < 2; ++k) {
+            const int m = m_base + (i + k) * 16 + er;
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            xv[k][j] = m < p.M ? *reinterpret_cast<const f32x4*>(p.X + (size_t)m * 512 + n_base + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j)
+              xv[k][j] = m < p.M ? *reinterpret_cast<const f32x4*>(p.X + (size_t)m * 512 + n_base + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i + k][j] += xv[k][j];
+          PT_PIN_BLOCK(i);
+          PT_PIN_BLOCK(i + 1);
         }
+      } else {
+        // bf16 residual stream (X == nullptr): the residual is the bf16 row this epilogue overwrites.  Loaded in the
+        // store layout (a lane reads the 8 consecutive bf16 it will write: in place is safe) and un-paired with the
+        // same v_permlane16_swap; four 16-row blocks per round trip in the registers two fp32 blocks took.
+        constexpr int XB = 4;
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+        for (int i0 = 0; i0 < MT; i0 += XB) {
+          u32x4 xr[XB][2];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i + k][j] += xv[k][j];
-        PT_PIN_BLOCK(i);
-        PT_PIN_BLOCK(i + 1);
+          for (int k = 0; k < XB; ++k) {
+            if (i0 + k < MT) {
+              const int m = m_base + (i0 + k) * 16 + er;
+#pragma unroll
+              for (int jj = 0; jj < 2; ++jj) {
+                const int n = wave * 64 + 16 * (2 * jj + (eq & 1)) + 8 * (eq >> 1);
+                xr[k][jj] = m < p.M ? *reinterpret_cast<const u32x4*>(p.Cb + (size_t)m * p.ldcb + n) : u32x4{0u, 0u, 0u, 0u};
+              }
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < XB; ++k) {
+            if (i0 + k < MT) {
+#pragma unroll
+              for (int jj = 0; jj < 2; ++jj) {
+                const auto a0 = __builtin_amdgcn_permlane16_swap(xr[k][jj][0], xr[k][jj][2], false, false);   // -> x0, y0
+                const auto a1 = __builtin_amdgcn_permlane16_swap(xr[k][jj][1], xr[k][jj][3], false, false);   // -> x1, y1
+                f32x4& lo = acc[i0 + k][2 * jj];
+                f32x4& hi = acc[i0 + k][2 * jj + 1];
+                lo[0] += __builtin_bit_cast(float, a0[0] << 16);
+                lo[1] += __builtin_bit_cast(float, a0[0] & 0xffff0000u);
+                lo[2] += __builtin_bit_cast(float, a1[0] << 16);
+                lo[3] += __builtin_bit_cast(float, a1[0] & 0xffff0000u);
+                hi[0] += __builtin_bit_cast(float, a0[1] << 16);
+                hi[1] += __builtin_bit_cast(float, a0[1] & 0xffff0000u);
+                hi[2] += __builtin_bit_cast(float, a1[1] << 16);
+                hi[3] += __builtin_bit_cast(float, a1[1] & 0xffff0000u);
+              }
+              PT_PIN_BLOCK(i0 + k);
+            }
+          }
+        }
       }
     }
     // one 16-row block: fp32 rows straight from the accumulators (16 rows x 64 B per instruction); bf16: accumulators j
     // and j+1 exchange 16-lane rows (v_permlane16_swap), afterwards a lane holds 8 consecutive bf16 columns
     // (column 16*(j + (eq & 1)) + 8*(eq >> 1) of the wave's 64)
-    float* outf = EPI == EPI_ADDLN ? p.X : (EPI == EPI_STD ? p.C : nullptr);
+    float* outf = RESB ? nullptr : EPI == EPI_ADDLN ? p.X : (EPI == EPI_STD ? p.C : nullptr);   // ADDLN with a bf16 residual stream: none
     const int ldf = EPI == EPI_ADDLN ? 512 : p.ldc;
     auto store_block = [&](int i) {
       const int m = m_base + i * 16 + er;
@@ -397,7 +444,7 @@ static int launch_row(const GemmBigArgs& a, hipStream_t s) {
   static int stagger_us = -1;
   if (stagger_us < 0) { const char* e = getenv("PT_GEMM_STAGGER"); stagger_us = e ? atoi(e) : 0; }
   GemmBigArgs b = a;
-  b.stagger = (EPI == EPI_ADDLN && ntiles > grid) ? stagger_us * 100 : 0;
+  b.stagger = ((EPI == EPI_ADDLN || EPI == EPI_ADDLN_B) && ntiles > grid) ? stagger_us * 100 : 0;
   void* tok = nullptr;
   if (prof_is_on()) prof_record_begin(s, a.flops > 0 ? a.flops : 2.0 * a.M * a.N * a.K, 7, &tok);
   PT_LAUNCH((gemm_row_kernel<MT, EPI>), dim3(grid), dim3(512), GR_SMEM, s, b, ntiles);
@@ -422,7 +469,8 @@ int launch_gemm_row(const GemmBigArgs& a, hipStream_t s) {
   const bool mt10 = force_mt ? force_mt == 10 : cost(160) <= cost(128);   // ties: the taller tile re-reads W less often
   if (a.epi == EPI_STD) return mt10 ? launch_row<10, EPI_STD>(a, s) : launch_row<8, EPI_STD>(a, s);
   if (a.epi == EPI_LNMOD) return mt10 ? launch_row<10, EPI_LNMOD>(a, s) : launch_row<8, EPI_LNMOD>(a, s);
-  return mt10 ? launch_row<10, EPI_ADDLN>(a, s) : launch_row<8, EPI_ADDLN>(a, s);
+  if (a.X) return mt10 ? launch_row<10, EPI_ADDLN>(a, s) : launch_row<8, EPI_ADDLN>(a, s);
+  return mt10 ? launch_row<10, EPI_ADDLN_B>(a, s) : launch_row<8, EPI_ADDLN_B>(a, s);
 }
 
 }  // namespace pt

@@ -112,7 +112,8 @@ struct GemmBigArgs {
   int relu, zero_to;
   // EPI_LNMOD: Cb = SiLU(norm(acc+bias) * style[label][0:512] + style[label][512:1024]); style = folded tables
   //            gamma*(1+scale) | beta*(1+scale)+shift per class (gamma/beta unused)
-  // EPI_ADDLN: X = LN(X + acc + bias; gamma,beta) in place (fp32), Cb = bf16 copy
+  // EPI_ADDLN: X = LN(X + acc + bias; gamma,beta) in place (fp32), Cb = bf16 copy;
+  //            X == nullptr: bf16 residual stream, Cb = LN(Cb + acc + bias) in place (row kernel only)
   const float* gamma; const float* beta;
   const float* style; const int64_t* label; int n_label, rows_per_clip, n_classes;
   float* X;

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void embed_pe_kernel(const int* __restrict__ i
     f32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = (float)((double)e[c + i] + (p1[c + i] + p2[c + i]));
-    *reinterpret_cast<f32x4*>(x + (size_t)row * DM + c) = o;
+    if (x) *reinterpret_cast<f32x4*>(x + (size_t)row * DM + c) = o;
     if (xb) {
       bf16x4 ob;
 #pragma unroll

@@ -6,6 +6,7 @@
 // The cross-attention K/V of every layer depend only on the condition, so the MaskGIT loop computes
 // them once and reuses them in all passes.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "transformer.h"
@@ -287,6 +288,16 @@ static int lin_b(const DevConv& c, const bf16_t* A, int lda, int rows, float* C,
 // bf16 mode, tail of every sub-layer: the sub-layer's last Linear `last` (A -> 512) with the style pre-op fused into
 // its epilogue (tmp = SiLU(LN(.)(1+scale)+shift), bf16), then the style Linear with the post-LN residual fused
 // (x = LN(x + .), fp32 + bf16 copy).  The pre-LayerNorm activations never reach HBM.
+// bf16 mode, residual stream: x lives in bf16 only, so the ADDLN epilogue reads and writes 1 KB per row instead of
+// reading 2 KB and writing 3 KB (116 -> 81 us per launch at 75,776 rows; the rounding of x once per sub-layer moves the
+// logits' relative error from 5.9e-3 to 6.4e-3, tests/test_gpu_bf16.py).  PT_RESID_BF16=0 keeps the fp32 residual
+// stream with a bf16 shadow (A/B measurements).
+static bool resid_bf16() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PT_RESID_BF16"); v = e ? atoi(e) : 1; }
+  return v == 1;
+}
+
 static int sublayer_tail_b(const DevConv& last, const bf16_t* A, int lda, bf16_t* tmp, const StyleW& st, const LNW& ln,
                            float* x, bf16_t* xb, int rows, int rows_per_clip, const int64_t* label, int n_label,
                            int n_classes, hipStream_t s) {
@@ -300,7 +311,7 @@ static int sublayer_tail_b(const DevConv& last, const bf16_t* A, int lda, bf16_t
   if (launch_gemm_big(a, s)) return 1;
   memset(&a, 0, sizeof(a));
   a.A = tmp; a.lda = DM; a.W = st.out.wb; a.bias = st.out.b; a.M = rows; a.N = DM; a.K = DM; a.Npad = st.out.Npad;
-  a.epi = EPI_ADDLN; a.X = x; a.Cb = xb; a.ldcb = DM; a.gamma = ln.g; a.beta = ln.b;
+  a.epi = EPI_ADDLN; a.X = resid_bf16() ? nullptr : x; a.Cb = xb; a.ldcb = DM; a.gamma = ln.g; a.beta = ln.b;
   a.flops = 2.0 * rows * DM * DM;
   return launch_gemm_big(a, s);
 }
@@ -510,7 +521,7 @@ static int predictor_memory(const Predictor& P, const float* cond_cl, int B, int
 static int predictor_pass(const Predictor& P, const int* ids, const int64_t* label, const PredMem& pm, TBufs& tb, int B,
                           int Tq, bool bf, float* logits, hipStream_t s) {
   const int N = Tq * P.groups, R = B * N;
-  if (launch_embed_pe(ids, P.tok_emb, P.pe, P.ppe, tb.x, tb.xb, R, N, P.groups, P.num_codes + 1, s)) return 1;
+  if (launch_embed_pe(ids, P.tok_emb, P.pe, P.ppe, bf && resid_bf16() ? nullptr : tb.x, tb.xb, R, N, P.groups, P.num_codes + 1, s)) return 1;
   for (int l = 0; l < P.n_layers; ++l)
     if (decoder_layer(P.layers[l], tb, pm.kv[l], B, N, Tq, label, B, P.n_classes, bf, s)) return 1;
   if (!bf) {
@@ -626,7 +637,7 @@ int refiner_forward(Model& m, const float* x, const float* condition, const floa
   } else {
     if (launch_cvt_f32_bf16(x_cl, ldx, xb_cl, ldx, rows, ldx, ldx, s)) return 1;
     if (launch_cvt_f32_bf16(c_cl, ldc, cb_cl, ldc, rows, ldc, ldc, s)) return 1;
-    if (lin_b(R.input_conv, xb_cl, ldx, rows, tb.x, DM, tb.xb, DM, ACT_NONE, 1.f, s, R.pe + DM, T)) return 1;
+    if (lin_b(R.input_conv, xb_cl, ldx, rows, resid_bf16() ? nullptr : tb.x, DM, tb.xb, DM, ACT_NONE, 1.f, s, R.pe + DM, T)) return 1;
     if (lin_b(R.audio_conv, cb_cl, ldc, rows, nullptr, 0, memb, DM, ACT_NONE, 1.f, s, R.pe + DM, T)) return 1;
     for (int l = 0; l < R.n_layers; ++l) {
       if (lin_b(R.layers[l].ca_kv, memb, DM, rows, nullptr, 0, kvb, 2 * DM, ACT_NONE, 1.f, s)) return 1;

@@ -96,6 +96,14 @@ def test_big_gemm_addln(M, K):
     scale = float(ref.abs().max())
     assert float((xd.cpu().double() - ref).abs().max()) / scale < 5e-6
     assert float((xb.cpu().double() - ref).abs().max()) / scale < 5e-3
+    # bf16 residual stream: x == NULL, the residual is the bf16 row that is overwritten
+    xr = x.bfloat16()
+    refb = _ln(xr.double() + A.double() @ W[:512].double().t() + bias[:512].double(), gamma.double(), beta.double())
+    xbd = xr.cuda()
+    _lib.check(L.pt_gemm_bf16_addln(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, K, Np, _lib.ptr(gd), _lib.ptr(btd),
+                                    None, _lib.ptr(xbd), _lib.stream()))
+    torch.cuda.synchronize()
+    assert float((xbd.cpu().double() - refb).abs().max()) / float(refb.abs().max()) < 5e-3
 
 
 def test_big_gemm_rejects_bad_geometry():
@@ -164,12 +172,18 @@ def test_persistent_ln_epilogues_match_reference_and_repeat(M, K):
         xb = torch.empty(M, 512, device="cuda", dtype=torch.bfloat16)
         _lib.check(L.pt_gemm_bf16_addln(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, K, Np, _lib.ptr(gd), _lib.ptr(btd), _lib.ptr(xd),
                                         _lib.ptr(xb), _lib.stream()))
+        xr = x0d.bfloat16()                                     # bf16 residual stream, updated in place
+        _lib.check(L.pt_gemm_bf16_addln(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, K, Np, _lib.ptr(gd), _lib.ptr(btd), None,
+                                        _lib.ptr(xr), _lib.stream()))
         torch.cuda.synchronize()
         if first is None:
-            first = (out, xd, xb)
+            first = (out, xd, xb, xr)
             assert float((out.double() - ref_mod).abs().max()) / float(ref_mod.abs().max()) < 5e-3
             sc = float(ref_add.abs().max())
             assert float((xd.double() - ref_add).abs().max()) / sc < 5e-6
             assert float((xb.double() - ref_add).abs().max()) / sc < 5e-3
+            ref_b = _ln(x0d.bfloat16().double() + v, gd.double(), btd.double())
+            assert float((xr.double() - ref_b).abs().max()) / float(ref_b.abs().max()) < 5e-3
         else:
-            assert torch.equal(out, first[0]) and torch.equal(xd, first[1]) and torch.equal(xb, first[2]), f"run {rep} differs"
+            assert torch.equal(out, first[0]) and torch.equal(xd, first[1]) and torch.equal(xb, first[2]) and \
+                torch.equal(xr, first[3]), f"run {rep} differs"

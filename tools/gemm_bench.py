@@ -11,7 +11,8 @@ shapes = [(9472, 512, 512), (9472, 1536, 512), (9472, 2048, 512), (9472, 512, 20
           (18944, 1024, 512), (8192, 8192, 8192)]
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
-for (M, N, K) in shapes:
+only_ln = os.environ.get("GEMM_BENCH_LN_ONLY") == "1"
+for (M, N, K) in ([] if only_ln else shapes):
     Np = (N + 127) // 128 * 128
     A = torch.randn(M, K, device="cuda").bfloat16()
     W = torch.randn(Np, K, device="cuda").bfloat16()
@@ -51,7 +52,9 @@ for (M, K) in [(75776, 512), (75776, 2048), (153600, 512)]:
                                                              _lib.ptr(style), _lib.ptr(label), M // 148 + 1, 148, 4,
                                                              _lib.ptr(out), _lib.stream())),
            "addln": lambda: _lib.check(L.pt_gemm_bf16_addln(_lib.ptr(A), K, _lib.ptr(W), _lib.ptr(bias), M, K, 512, _lib.ptr(gamma),
-                                                             _lib.ptr(beta), _lib.ptr(x), _lib.ptr(out), _lib.stream()))}
+                                                             _lib.ptr(beta), _lib.ptr(x), _lib.ptr(out), _lib.stream())),
+           "addln_b": lambda: _lib.check(L.pt_gemm_bf16_addln(_lib.ptr(A), K, _lib.ptr(W), _lib.ptr(bias), M, K, 512, _lib.ptr(gamma),
+                                                               _lib.ptr(beta), None, _lib.ptr(out), _lib.stream()))}
     for name, run in fns.items():
         for _ in range(3):
             run()
