@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--dtype", choices=("bf16", "f32"), default="bf16",
                     help="arithmetic of the predictor/refiner transformers (conv stacks and PQ stay fp32)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from one captured HIP graph (probtalk_amd/graphs.py): for small, launch-bound batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -149,8 +151,13 @@ def main():
     ids = torch.randint(0, 4, (B,), device=dev, generator=g)
     gather = OutputGatherer(world, (B, 376, T), dev) if world > 1 else None
 
+    graphed = None
+    if a.graph:
+        from probtalk_amd.graphs import GraphedHolisticStep
+        graphed = GraphedHolisticStep(pred, ref, B, T)
+
     def step():
-        out = holistic_step(pred, ref, aud, gt, mask, ids, sync=False)
+        out = graphed(aud, gt, mask, ids) if graphed else holistic_step(pred, ref, aud, gt, mask, ids, sync=False)
         if gather is not None:
             gather.submit(out)          # RCCL all_gather of the outputs on a side stream, overlapped with the next step
         return out
@@ -184,7 +191,7 @@ def main():
         "config": {"workload": "configs[3] per-GPU share: full holistic pipeline (AudEnc + motion-context encoder + "
                                "8-pass MaskGIT predictor + PQ gather/decode + refiner); "
                                + ("bf16 MFMA operands / fp32 accumulate in the transformers, condition encoders and PQ-VAE decoder" if a.dtype == "bf16" else "fp32"),
-                   "clips_per_step_per_gpu": B, "frames_per_clip": T,
+                   "clips_per_step_per_gpu": B, "frames_per_clip": T, "launch": "hip graph replay" if a.graph else "eager",
                    "parallelism": f"dp{world}: clips sharded over ranks, outputs all_gathered over RCCL"},
     }
 
@@ -236,6 +243,7 @@ def main():
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()          # rank 0 is still in its roofline pass: leave together
         dist.destroy_process_group()
 
 

@@ -91,6 +91,12 @@ int pt_predictor_sample(pt_model* m, const int64_t* label, const float* conditio
  * reference draws the Gumbel noise on the CPU and copies it each pass, PTransformer.py:697-698).  Same seed, same codes. */
 int pt_predictor_sample_seeded(pt_model* m, const int64_t* label, const float* condition, unsigned long long seed, int steps,
                                int B, int Tq, int32_t* codes_out, float* logits_out, void* ws, size_t ws_bytes, void* stream);
+/* pt_predictor_sample_seeded with the seed read from device memory by the kernels (one uint64 at seed_dev): the call
+ * bakes no per-call value into its launches, so a caller can capture it into a HIP graph once and replay it with a new
+ * seed each time by writing seed_dev first.  No counterpart in the reference (eager PyTorch, host RNG per pass). */
+int pt_predictor_sample_seed_dev(pt_model* m, const int64_t* label, const float* condition, const unsigned long long* seed_dev,
+                                 int steps, int B, int Tq, int32_t* codes_out, float* logits_out, void* ws, size_t ws_bytes,
+                                 void* stream);
 /* The noise pt_predictor_sample_seeded uses in pass `step`, written out: noise_q (B,N,V), noise_g (B,N).  Feeding these to
  * pt_predictor_sample reproduces the seeded codes (test hook; also a stand-alone Exp(1) / Gumbel generator). */
 int pt_maskgit_noise(unsigned long long seed, int step, int B, int N, int V, float* noise_q, float* noise_g, void* stream);

@@ -181,6 +181,13 @@ int pt_predictor_sample_seeded(pt_model* h, const int64_t* label, const float* c
   return predictor_sample(h->m, label, condition, nullptr, nullptr, steps, B, Tq, codes_out, logits_out, ws, ws_bytes,
                           (hipStream_t)stream, seed);
 }
+int pt_predictor_sample_seed_dev(pt_model* h, const int64_t* label, const float* condition, const unsigned long long* seed_dev,
+                                 int steps, int B, int Tq, int32_t* codes_out, float* logits_out, void* ws, size_t ws_bytes,
+                                 void* stream) {
+  PT_CHECK(h && label && condition && codes_out && seed_dev, "pt_predictor_sample_seed_dev: null argument");
+  return predictor_sample(h->m, label, condition, nullptr, nullptr, steps, B, Tq, codes_out, logits_out, ws, ws_bytes,
+                          (hipStream_t)stream, 0, seed_dev);
+}
 int pt_maskgit_noise(unsigned long long seed, int step, int B, int N, int V, float* noise_q, float* noise_g, void* stream) {
   return launch_maskgit_noise(seed, step, B, N, V, noise_q, noise_g, (hipStream_t)stream);
 }

@@ -466,11 +466,26 @@ int launch_gemm_row(const GemmBigArgs& a, hipStream_t s) {
     const long tiles = (a.M + bm - 1) / bm;
     return ((tiles + gr_num_cus - 1) / gr_num_cus) * (long)bm;
   };
-  const bool mt10 = force_mt ? force_mt == 10 : cost(160) <= cost(128);   // ties: the taller tile re-reads W less often
-  if (a.epi == EPI_STD) return mt10 ? launch_row<10, EPI_STD>(a, s) : launch_row<8, EPI_STD>(a, s);
-  if (a.epi == EPI_LNMOD) return mt10 ? launch_row<10, EPI_LNMOD>(a, s) : launch_row<8, EPI_LNMOD>(a, s);
-  if (a.X) return mt10 ? launch_row<10, EPI_ADDLN>(a, s) : launch_row<8, EPI_ADDLN>(a, s);
-  return mt10 ? launch_row<10, EPI_ADDLN_B>(a, s) : launch_row<8, EPI_ADDLN_B>(a, s);
+  int mt = force_mt ? force_mt : (cost(160) <= cost(128) ? 10 : 8);       // ties: the taller tile re-reads W less often
+  if (!force_mt) {
+    // fewer tiles than CUs: the launch is one round whatever the tile height, and its length is the K loop of one tile
+    // (latency per K-tile, not MFMA work), so shorter tiles on more CUs finish sooner
+    if ((a.M + 63) / 64 <= gr_num_cus) mt = 4;
+    if ((a.M + 31) / 32 <= gr_num_cus) mt = 2;
+  }
+  PT_CHECK(mt == 2 || mt == 4 || mt == 8 || mt == 10, "gemm_row: tile height 16*%d not built (PT_GEMM_ROW_MT = 2, 4, 8 or 10)", mt);
+#define PT_ROW_DISPATCH(E)                                            \
+  switch (mt) {                                                       \
+    case 2: return launch_row<2, E>(a, s);                            \
+    case 4: return launch_row<4, E>(a, s);                            \
+    case 8: return launch_row<8, E>(a, s);                            \
+    default: return launch_row<10, E>(a, s);                          \
+  }
+  if (a.epi == EPI_STD) PT_ROW_DISPATCH(EPI_STD)
+  if (a.epi == EPI_LNMOD) PT_ROW_DISPATCH(EPI_LNMOD)
+  if (a.X) PT_ROW_DISPATCH(EPI_ADDLN)
+  PT_ROW_DISPATCH(EPI_ADDLN_B)
+#undef PT_ROW_DISPATCH
 }
 
 }  // namespace pt

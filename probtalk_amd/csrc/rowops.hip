@@ -214,8 +214,10 @@ __global__ __launch_bounds__(256) void maskgit_step_kernel(const float* __restri
                                                            const float* __restrict__ noise_q,
                                                            const float* __restrict__ noise_g, int* __restrict__ ids,
                                                            int N, int V, int mask_id, int want_mask, float temp,
-                                                           unsigned long long seed, int step) {
+                                                           unsigned long long seed, int step,
+                                                           const unsigned long long* __restrict__ seed_dev) {
   extern __shared__ float sm[];
+  if (seed_dev) seed = *seed_dev;                    // seed kept in device memory: a captured graph replays with new seeds
   float* conf = sm;                                  // [N]
   int* samp = reinterpret_cast<int*>(conf + N);      // [N]
   __shared__ int unknown_cnt;
@@ -267,11 +269,12 @@ __global__ __launch_bounds__(256) void maskgit_step_kernel(const float* __restri
   }
 }
 int launch_maskgit_step(const float* logits, const float* noise_q, const float* noise_g, int* ids, int B, int N, int V,
-                        int mask_id, int want_mask, float temp, hipStream_t s, unsigned long long seed, int step) {
+                        int mask_id, int want_mask, float temp, hipStream_t s, unsigned long long seed, int step,
+                        const unsigned long long* seed_dev) {
   PT_CHECK(N > 0 && N <= 8192, "maskgit_step: N=%d out of range", N);
   PT_CHECK((noise_q == nullptr) == (noise_g == nullptr), "maskgit_step: both noise tensors or neither");
   PT_LAUNCH(maskgit_step_kernel, dim3(B), dim3(256), (size_t)N * 8, s, logits, noise_q, noise_g, ids, N, V,
-                     mask_id, want_mask, temp, seed, step);
+                     mask_id, want_mask, temp, seed, step, seed_dev);
   return 0;
 }
 

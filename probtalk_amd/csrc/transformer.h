@@ -12,7 +12,7 @@ int predictor_logits(Model& m, const int32_t* ids, const int64_t* label, const f
                      float* logits, void* ws, size_t ws_bytes, hipStream_t s);
 int predictor_sample(Model& m, const int64_t* label, const float* condition, const float* noise_q, const float* noise_g,
                      int steps, int B, int Tq, int32_t* codes_out, float* logits_out, void* ws, size_t ws_bytes, hipStream_t s,
-                     unsigned long long seed = 0);
+                     unsigned long long seed = 0, const unsigned long long* seed_dev = nullptr);
 size_t refiner_workspace_bytes(const Model& m, int B, int T);
 int refiner_forward(Model& m, const float* x, const float* condition, const float* mask, const int64_t* label,
                     int n_label, int B, int T, float* out, void* ws, size_t ws_bytes, hipStream_t s);

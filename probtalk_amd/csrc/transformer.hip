@@ -26,7 +26,8 @@ int launch_attention_bf16(const unsigned short* Q, int ldq, const unsigned short
                           int ldv, unsigned short* O, int ldo, int B, int Nq, int Nk, int H, hipStream_t s);
 int launch_mask_onehot(const float* mask, float* cond, int rows, int ld, int c0, int zero_to, hipStream_t s);
 int launch_maskgit_step(const float* logits, const float* noise_q, const float* noise_g, int* ids, int B, int N, int V,
-                        int mask_id, int want_mask, float temp, hipStream_t s, unsigned long long seed, int step);
+                        int mask_id, int want_mask, float temp, hipStream_t s, unsigned long long seed, int step,
+                        const unsigned long long* seed_dev);
 int launch_fill_i32(int* p, int v, size_t n, hipStream_t s);
 int launch_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                      int B, int Nq, int Nk, int H, hipStream_t s);
@@ -264,7 +265,10 @@ static int lin_b(const DevConv& c, const bf16_t* A, int lda, int rows, float* C,
                  float slope, hipStream_t s, const double* pe = nullptr, int period = 0) {
   PT_CHECK(c.wb != nullptr, "bf16 weights were not packed for this layer");
   PT_CHECK(lda >= c.Kb, "lin_b: input leading dim %d < packed K %d", lda, c.Kb);
-  if (c.N >= 256 && c.N % 8 == 0 && (act == ACT_NONE || slope == 0.f)) {
+  static int small_rows = -1;
+  if (small_rows < 0) { const char* e = getenv("PT_SMALLM_ROWS"); small_rows = e ? atoi(e) : 2048; }
+  const bool small = c.N != 512 && rows <= small_rows;     // few 256 x 256 tiles: the 4-wave kernel's smaller tiles fill more CUs
+  if (!small && c.N >= 256 && c.N % 8 == 0 && (act == ACT_NONE || slope == 0.f)) {
     GemmBigArgs a;
     memset(&a, 0, sizeof(a));
     a.A = A; a.lda = lda; a.W = c.wb; a.bias = c.b; a.M = rows; a.N = c.N; a.K = c.Kb; a.Npad = c.Npad;
@@ -549,10 +553,11 @@ int predictor_logits(Model& m, const int32_t* ids, const int64_t* label, const f
   return predictor_pass(P, ids, label, pm, tb, B, Tq, bf, logits, s);
 }
 
-// noise_q / noise_g NULL: the MaskGIT step kernel generates both draws itself from (seed, step, element)
+// noise_q / noise_g NULL: the MaskGIT step kernel generates both draws itself from (seed, step, element); seed_dev, when
+// given, is where the kernels read the seed from at run time (graph replay with a fresh seed per replay)
 int predictor_sample(Model& m, const int64_t* label, const float* condition, const float* noise_q, const float* noise_g,
                      int steps, int B, int Tq, int32_t* codes_out, float* logits_out, void* ws, size_t ws_bytes,
-                     hipStream_t s, unsigned long long seed) {
+                     hipStream_t s, unsigned long long seed, const unsigned long long* seed_dev) {
   PT_CHECK(m.finalized && m.pred, "predictor_sample: wrong or unfinalized model");
   PT_CHECK(B > 0 && Tq > 0 && steps > 0, "predictor_sample: empty input B=%d T'=%d steps=%d", B, Tq, steps);
   const Predictor& P = *m.pred;
@@ -579,7 +584,7 @@ int predictor_sample(Model& m, const int64_t* label, const float* condition, con
     const int want = (int)floorf((float)N * mask_ratio);
     const float temp = (float)(4.5 * (1.0 - ratio));
     if (launch_maskgit_step(lt, noise_q ? noise_q + (size_t)t * R * V : nullptr, noise_g ? noise_g + (size_t)t * R : nullptr, ids, B,
-                            N, V, V, want, temp, s, seed, t)) return 1;
+                            N, V, V, want, temp, s, seed, t, seed_dev)) return 1;
   }
   PT_HIP(hipMemcpyAsync(codes_out, ids, R * sizeof(int), hipMemcpyDeviceToDevice, s));
   return 0;

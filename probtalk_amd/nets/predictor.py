@@ -170,7 +170,7 @@ class TrainWrapper(TrainWrapperBaseClass):
             return torch.cat([gt_poses[:, :self.each_dim[0]], gt_poses[:, -self.each_dim[3]:]], 1)
         return gt_poses
 
-    def _infer(self, aud, id, B, gt_poses, mask, noise=None, sync=True):
+    def _infer(self, aud, id, B, gt_poses, mask, noise=None, sync=True, seed=None):
         gt_poses = self._select(gt_poses)
         aud = aud.repeat(B, 1, 1) if aud.shape[0] != B else aud
         id = torch.as_tensor(id).to('cuda').reshape(-1)
@@ -183,22 +183,22 @@ class TrainWrapper(TrainWrapperBaseClass):
         start = time.time()
         input_poses = interp_blend(None, T, gt, mk, premask=False)  # gt_poses * mask
         audio = self.AudEnc(aud)
-        codes = self.Predictor(input_poses, None, mk, id, audio, None, 1, noise=noise)
+        codes = self.Predictor(input_poses, None, mk, id, audio, None, 1, noise=noise, seed=seed)
         pred_poses = self.VQ.decode_codes(codes)                    # quantize_all + transpose + decode
         pred_poses = interp_blend(pred_poses, T, input_poses, mk, premask=False)   # input_poses*mask + pred*(1-mask)
         if sync:
             torch.cuda.synchronize()   # the reference omits this one, so its timings undercount (predictor.py:443)
         return pred_poses, codes, time.time() - start
 
-    def infer_on_batch(self, aud, text, id, B, gt_poses, mask, noise=None, sync=True, **kwargs):
+    def infer_on_batch(self, aud, text, id, B, gt_poses, mask, noise=None, sync=True, seed=None, **kwargs):
         """predictor.py:398-448 -> (poses (B,C,T), seconds).  sync=False enqueues only (seconds ~ 0)."""
         assert self.args.infer, "train mode"
         self._eval()
-        poses, _, sec = self._infer(aud, id, B, gt_poses, mask, noise, sync)
+        poses, _, sec = self._infer(aud, id, B, gt_poses, mask, noise, sync, seed)
         return poses, sec
 
-    def infer_to_code(self, aud, text, id, B, gt_poses, mask, noise=None, **kwargs):
+    def infer_to_code(self, aud, text, id, B, gt_poses, mask, noise=None, seed=None, **kwargs):
         """predictor.py:597-647 -> (poses, codes (B,T',G), seconds)."""
         assert self.args.infer, "train mode"
         self._eval()
-        return self._infer(aud, id, B, gt_poses, mask, noise)
+        return self._infer(aud, id, B, gt_poses, mask, noise, seed=seed)

@@ -163,7 +163,9 @@ class PTransformer(nn.Module):
         g ~ Gumbel(0,1) of shape (T,B,N)): the parity mode.  By default both are generated inside the MaskGIT step kernel
         from a 64-bit seed (`seed=`, else drawn from torch's CPU generator, so torch.manual_seed makes runs repeatable):
         no noise tensors and no host RNG call per pass (the reference draws the Gumbel noise on the CPU and copies it
-        each pass, PTransformer.py:697-698)."""
+        each pass, PTransformer.py:697-698).  A one-element int64 CUDA tensor as `seed` is read by the kernels at run
+        time: nothing of the call depends on a host value then, so it can be captured into a HIP graph and replayed with a
+        new seed written to that tensor (probtalk_amd/graphs.py)."""
         _train_guard(self, "PTransformer.sample_good")
         if mode != "cosine":
             raise NotImplementedError("sample_good is only called with the cosine schedule")
@@ -176,7 +178,12 @@ class PTransformer(nn.Module):
         codes = torch.empty(B, Tq, self.groups, dtype=torch.int32, device=cond.device)
         logits = torch.empty(T, B, N, self.num_code, device=cond.device) if return_logits else None
         ws = h.workspace(L.pt_predictor_workspace_bytes(h.h, B, Tq * 8))
-        if noise is None:
+        if noise is None and torch.is_tensor(seed):
+            if not (seed.is_cuda and seed.dtype == torch.int64 and seed.numel() == 1):
+                raise RuntimeError("sample_good: a tensor seed must be one int64 element on the GPU")
+            check(L.pt_predictor_sample_seed_dev(h.h, ptr(lab), ptr(cond), ptr(seed), T, B, Tq, ptr(codes), ptr(logits), ptr(ws),
+                                                 ws.numel(), stream()))
+        elif noise is None:
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             check(L.pt_predictor_sample_seeded(h.h, ptr(lab), ptr(cond), int(seed), T, B, Tq, ptr(codes), ptr(logits), ptr(ws),
@@ -263,12 +270,12 @@ class PredictorNet(_HandleOwner, nn.Module):
         return cond
 
     def forward(self, masked_motion, state, mask, label, audio, text, epoch_ratio, input_codes=None,
-                distribution=False, noise=None):
+                distribution=False, noise=None, seed=None):
         _train_guard(self, "PredictorNet.forward")
         if distribution:
             raise NotImplementedError("distribution=True calls a method the reference does not define")
         cond = self.condition(masked_motion, mask, audio)
-        return self.decoder.sample_good(label, cond, input_codes, T=self.T, noise=noise)
+        return self.decoder.sample_good(label, cond, input_codes, T=self.T, noise=noise, seed=seed)
 
 
 class RTransformer(_HandleOwner, nn.Module):

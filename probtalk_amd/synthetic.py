@@ -48,11 +48,11 @@ def build_pipeline(seed=0, tmpdir=None):
     return pred, ref
 
 
-def holistic_step(pred, ref, aud, gt_poses, mask, ids, noise=None, sync=False):
+def holistic_step(pred, ref, aud, gt_poses, mask, ids, noise=None, sync=False, seed=None):
     """One pass of the full path over one batch (test_holisticbody.py:248-253 via ai1.py:51-57):
     predictor.infer_on_batch -> refiner.infer_on_batch(pred_poses=...).  Returns (B,376,T) poses."""
     B = aud.shape[0]
     body, _ = pred.infer_on_batch(aud=aud, text=None, id=ids, B=B, gt_poses=gt_poses, mask=mask, noise=noise,
-                                  sync=sync)
+                                  sync=sync, seed=seed)
     out, _ = ref.infer_on_batch(aud=aud, B=B, id=ids, gt_poses=gt_poses, mask=mask, pred_poses=body, sync=sync)
     return out

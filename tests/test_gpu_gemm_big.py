@@ -45,7 +45,8 @@ def test_big_gemm_plain(M, N, K, relu):
     assert bool((C[:, N:] == 7.0).all()) and bool((Cb[:, N:] == 7.0).all())            # nothing outside [0, N)
 
 
-@pytest.mark.parametrize("M,K,ncls", [(148 * 3, 512, 4), (300 * 2 + 17, 2048, 4), (148 * 5, 512, 6)])
+@pytest.mark.parametrize("M,K,ncls", [(148 * 3, 512, 4), (300 * 2 + 17, 2048, 4), (148 * 5, 512, 6), (9472, 512, 4),
+                                      (20000, 2048, 4)])
 def test_big_gemm_lnmod(M, K, ncls):
     """ncls = 6 takes the two-stage kernel (the phase-pipelined row kernel keeps at most 4 classes of tables in LDS)."""
     L = _lib.lib()
@@ -79,7 +80,7 @@ def test_big_gemm_lnmod(M, K, ncls):
     assert float((out1.cpu().double() - ref1).abs().max()) / float(ref1.abs().max()) < 5e-3
 
 
-@pytest.mark.parametrize("M,K", [(148 * 2 + 5, 512), (1024, 512)])
+@pytest.mark.parametrize("M,K", [(148 * 2 + 5, 512), (1024, 512), (9472, 2048), (20000, 512)])   # tile heights 32, 32, 64, 128
 def test_big_gemm_addln(M, K):
     L = _lib.lib()
     A, W, bias, Np = _mk(M, 512, K, 23)

@@ -40,7 +40,10 @@ for (M, N, K) in ([] if only_ln else shapes):
         print(f"M={M:6d} N={N:5d} K={K:5d} {mode:8s} {us:9.1f} us  {2.0*M*N*K/us/1e6:8.1f} TF  err {err:.1e}", flush=True)
 
 # fused LayerNorm epilogues (N = 512)
-for (M, K) in [(75776, 512), (75776, 2048), (153600, 512)]:
+ln_shapes = [(75776, 512), (75776, 2048), (153600, 512)]
+if os.environ.get("GEMM_BENCH_LN_M"):
+    ln_shapes = [(int(m), k) for m in os.environ["GEMM_BENCH_LN_M"].split(",") for k in (512, 2048)]
+for (M, K) in ln_shapes:
     A = torch.randn(M, K, device="cuda").bfloat16()
     W = (torch.randn(512, K, device="cuda") * K ** -0.5).bfloat16()
     bias, gamma, beta = (torch.randn(512, device="cuda") for _ in range(3))
