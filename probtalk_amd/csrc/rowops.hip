@@ -210,7 +210,7 @@ int launch_maskgit_noise(unsigned long long seed, int step, int B, int N, int V,
   return 0;
 }
 
-__global__ __launch_bounds__(256) void maskgit_step_kernel(const float* __restrict__ logits,
+__global__ __launch_bounds__(1024) void maskgit_step_kernel(const float* __restrict__ logits,
                                                            const float* __restrict__ noise_q,
                                                            const float* __restrict__ noise_g, int* __restrict__ ids,
                                                            int N, int V, int mask_id, int want_mask, float temp,
@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256) void maskgit_step_kernel(const float* __restri
   if (tid == 0) unknown_cnt = 0;
   __syncthreads();
   int my_unknown = 0;
-  for (int n = wave; n < N; n += 4) {
+  const int nwaves = blockDim.x >> 6;
+  for (int n = wave; n < N; n += nwaves) {
     const float* lg = logits + ((size_t)b * N + n) * V;
     const size_t qbase = ((size_t)b * N + n) * V;            // noise_q == NULL: counter-based noise (seed, step)
     float mx = -INFINITY;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void maskgit_step_kernel(const float* __restri
   int k = unknown_cnt - 1;
   k = k < want_mask ? k : want_mask;
   k = k < 0 ? 0 : k;
-  for (int n = tid; n < N; n += 256) {
+  for (int n = tid; n < N; n += blockDim.x) {
     const float c = conf[n];
     int le = 0;
     for (int m = 0; m < N; ++m) le += conf[m] <= c;
@@ -273,7 +274,8 @@ int launch_maskgit_step(const float* logits, const float* noise_q, const float* 
                         const unsigned long long* seed_dev) {
   PT_CHECK(N > 0 && N <= 8192, "maskgit_step: N=%d out of range", N);
   PT_CHECK((noise_q == nullptr) == (noise_g == nullptr), "maskgit_step: both noise tensors or neither");
-  PT_LAUNCH(maskgit_step_kernel, dim3(B), dim3(256), (size_t)N * 8, s, logits, noise_q, noise_g, ids, N, V,
+  // few clips: 16 waves per clip (one workgroup per clip is all the parallelism there is); many clips: 4 waves, 4+ clips per CU
+  PT_LAUNCH(maskgit_step_kernel, dim3(B), dim3(B <= 256 ? 1024 : 256), (size_t)N * 8, s, logits, noise_q, noise_g, ids, N, V,
                      mask_id, want_mask, temp, seed, step, seed_dev);
   return 0;
 }
