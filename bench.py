@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--dtype", choices=("bf16", "f32"), default="bf16",
                     help="arithmetic of the predictor/refiner transformers (conv stacks and PQ stay fp32)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the step's clips are split over (contiguous shares, joined before the step returns); "
+                         "1 = the whole batch as one launch sequence")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from one captured HIP graph (probtalk_amd/graphs.py): for small, launch-bound batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -156,8 +159,10 @@ def main():
         from probtalk_amd.graphs import GraphedHolisticStep
         graphed = GraphedHolisticStep(pred, ref, B, T)
 
+    streams = [torch.cuda.Stream(device=dev) for _ in range(a.streams)] if a.streams > 1 and not a.graph else None
+
     def step():
-        out = graphed(aud, gt, mask, ids) if graphed else holistic_step(pred, ref, aud, gt, mask, ids, sync=False)
+        out = graphed(aud, gt, mask, ids) if graphed else holistic_step(pred, ref, aud, gt, mask, ids, sync=False, streams=streams)
         if gather is not None:
             gather.submit(out)          # RCCL all_gather of the outputs on a side stream, overlapped with the next step
         return out
@@ -191,7 +196,7 @@ def main():
         "config": {"workload": "configs[3] per-GPU share: full holistic pipeline (AudEnc + motion-context encoder + "
                                "8-pass MaskGIT predictor + PQ gather/decode + refiner); "
                                + ("bf16 MFMA operands / fp32 accumulate in the transformers, condition encoders and PQ-VAE decoder" if a.dtype == "bf16" else "fp32"),
-                   "clips_per_step_per_gpu": B, "frames_per_clip": T, "launch": "hip graph replay" if a.graph else "eager",
+                   "clips_per_step_per_gpu": B, "frames_per_clip": T, "launch": "hip graph replay" if a.graph else (f"eager, clips split over {a.streams} HIP streams" if streams else "eager, one stream"),
                    "parallelism": f"dp{world}: clips sharded over ranks, outputs all_gathered over RCCL"},
     }
 

@@ -175,10 +175,19 @@ class Handle:
         self._ws = None
 
     def workspace(self, nbytes):
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = None
-            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device="cuda")
-        return self._ws
+        """Scratch arena of the library calls on this model, one per HIP stream: calls on one stream run in order and
+        share it, calls on different streams (probtalk_amd.synthetic.holistic_step(streams=...)) must not."""
+        key = torch.cuda.current_stream().cuda_stream
+        pool = self.__dict__.setdefault("_ws_by_stream", {})
+        ws = pool.get(key)
+        if ws is None or ws.numel() < nbytes:
+            pool[key] = None
+            for k in list(pool)[:-8]:          # streams that are gone: their arenas go back to the allocator
+                if k != key:
+                    del pool[k]
+            ws = pool[key] = torch.empty(int(nbytes), dtype=torch.uint8, device="cuda")
+        self._ws = ws
+        return ws
 
     def __del__(self):
         try:
