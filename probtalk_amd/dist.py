@@ -104,6 +104,10 @@ class GradientReducer:
         # reduce() launches whatever is left (buckets holding a parameter without gradient) and waits for all of them
         self._bucket_of = {id(p): i for i, bk in enumerate(self.buckets) for p in bk}
         self._ready = [0] * len(self.buckets)
+        # gradients a bucket waits for before it leaves: all of its parameters at first; after a step, the ones that
+        # received a gradient in that step (parameters the graph never reaches would otherwise hold every bucket back
+        # until reduce(); the graph is the same on every rank and every step)
+        self._expect = [len(bk) for bk in self.buckets]
         self._pending = {}
         self.launched_in_backward = 0
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if overlap else []
@@ -120,14 +124,17 @@ class GradientReducer:
             return
         flat = self._flat_for(i, sum(p.numel() for p in live), live[0].grad)
         torch.cat([p.grad.reshape(-1) for p in live], out=flat)
-        self._pending[i] = (dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, live)
+        # gloo (CPU rehearsals, or several ranks on one GPU in tests) gets a host copy: its own staging of device tensors
+        # deadlocked with several collectives in flight on this ROCm build; RCCL reduces the device buffer in place
+        msg = flat.cpu() if flat.is_cuda and dist.get_backend() == "gloo" else flat
+        self._pending[i] = (dist.all_reduce(msg, op=dist.ReduceOp.SUM, async_op=True), flat, live, msg)
 
     def _on_grad(self, p):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         i = self._bucket_of[id(p)]
         self._ready[i] += 1
-        if self._ready[i] == len(self.buckets[i]) and i not in self._pending:
+        if self._ready[i] == self._expect[i] and i not in self._pending:
             self._launch(i)
             self.launched_in_backward += 1
 
@@ -142,8 +149,11 @@ class GradientReducer:
             if i not in self._pending:
                 self._launch(i)
         for i in sorted(self._pending):
-            work, flat, live = self._pending[i]
+            work, flat, live, msg = self._pending[i]
+            self._expect[i] = len(live)
             work.wait()
+            if msg is not flat:
+                flat.copy_(msg)
             flat.mul_(1.0 / world)
             off = 0
             for p in live:
@@ -152,9 +162,39 @@ class GradientReducer:
         self._pending = {}
         self._ready = [0] * len(self.buckets)
 
+    def agree(self, *scalars):
+        """Rank 0's values of small device tensors (gradient norms, clip coefficients) replace everyone's, in place.
+        The norm kernels sum with floating-point atomics, so two ranks holding the same averaged gradient can differ in
+        the last bit of the norm; a clip coefficient that differs between ranks would let the replicas drift apart."""
+        if dist.get_world_size() == 1 or not scalars:
+            return
+        flat = torch.cat([t.detach().reshape(-1).float() for t in scalars])
+        msg = flat.cpu() if flat.is_cuda and dist.get_backend() == "gloo" else flat
+        dist.broadcast(msg, src=0)
+        if msg is not flat:
+            flat.copy_(msg)
+        off = 0
+        for t in scalars:
+            t.detach().copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+
     def sync_buffers(self):
         """Rank 0's BatchNorm running statistics win, as device 0's do under nn.DataParallel."""
         if dist.get_world_size() == 1:
             return
-        for b in self.buffers:
-            dist.broadcast(b, src=0)
+        if not self.buffers:
+            return
+        # one flat message per dtype instead of one per buffer (a BatchNorm layer has two 256-float buffers)
+        for dt in {b.dtype for b in self.buffers}:
+            bs = [b for b in self.buffers if b.dtype == dt]
+            flat = torch.cat([b.reshape(-1) for b in bs])
+            if flat.is_cuda and dist.get_backend() == "gloo":
+                host = flat.cpu()
+                dist.broadcast(host, src=0)
+                flat.copy_(host)
+            else:
+                dist.broadcast(flat, src=0)
+            off = 0
+            for b in bs:
+                b.copy_(flat[off:off + b.numel()].view_as(b))
+                off += b.numel()

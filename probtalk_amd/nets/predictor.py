@@ -152,6 +152,8 @@ class TrainWrapper(TrainWrapperBaseClass):
             self._reducer.sync_buffers()
         grad_ae, coef_ae = train_ops.clip_grad_norm(pa, max_norm)
         grad_p, coef_p = train_ops.clip_grad_norm(pp, max_norm)
+        if multi:
+            self._reducer.agree(grad_ae, coef_ae, grad_p, coef_p)
         coefs = {p: coef_ae for p in pa}
         coefs.update({p: coef_p for p in pp})
         self.generator_optimizer.step(coefs)

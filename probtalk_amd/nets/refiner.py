@@ -132,6 +132,8 @@ class TrainWrapper(TrainWrapperBaseClass):
         if multi:
             self._reducer.reduce()
         grad_HF, coef = train_ops.clip_grad_norm(params, self.config.Train.max_gradient_norm)
+        if multi:
+            self._reducer.agree(grad_HF, coef)
         self.generator_optimizer.step({p: coef for p in params})
         rt.invalidate()
         s = sums.tolist()

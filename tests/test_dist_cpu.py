@@ -109,7 +109,9 @@ def _overlap_worker(rank, world, port):
             for p in w:
                 h = torch.tanh(h @ p)
             h.pow(2).sum().backward()
-            assert red.launched_in_backward == 3 * (step + 1)        # the three complete buckets went out during backward
+            # step 0: the three complete buckets go out during backward; from then on the reducer knows that `unused`
+            # never receives a gradient and its bucket leaves during backward as well
+            assert red.launched_in_backward == 3 + 4 * step
             red.reduce()
             want = []
             for r in range(world):
@@ -122,6 +124,10 @@ def _overlap_worker(rank, world, port):
             for i, p in enumerate(w):
                 assert torch.allclose(p.grad, sum(wr[i] for wr in want) / world, atol=1e-5)
             assert unused.grad is None
+        # rank 0's small tensors win (clip coefficients must be identical on every rank)
+        a, b = torch.tensor([1.0 + rank]), torch.tensor([[10.0 * (rank + 1), 3.0]])
+        red.agree(a, b)
+        assert a.tolist() == [1.0] and b.tolist() == [[10.0, 3.0]]
     finally:
         dist.destroy_process_group()
 
