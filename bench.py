@@ -128,11 +128,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of the N > 1 control flow on one GPU
+    if backend == "gloo":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
     if a.workload == "train":
         train_bench(a, rank, world, dev)
         if world > 1:

@@ -61,7 +61,12 @@ class OutputGatherer:
         ev.record()
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ev)
-            dist.all_gather_into_tensor(buf, out)
+            if dist.get_backend() == "gloo":            # rehearsal on one GPU: gloo gets host copies (see GradientReducer)
+                parts = [torch.empty(out.shape, dtype=out.dtype) for _ in range(self.world)]
+                dist.all_gather(parts, out.cpu())
+                buf.copy_(torch.cat(parts))
+            else:
+                dist.all_gather_into_tensor(buf, out)
         out.record_stream(self.stream)
         return buf
 
