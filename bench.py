@@ -230,6 +230,9 @@ def main():
             "launches_per_step": tot_n, "avg_launch_ms": tot_ms / max(tot_n, 1),
             "algorithmic_gflop_per_launch": tot_fl / max(tot_n, 1) / 1e9,
             "kernel_ms_per_step": tot_ms,
+            "timed_as": "every launch of one untimed extra step on ONE stream at the full per-GPU batch, HIP events on the "
+                        "launch stream; the rocprofv3 --kernel-trace --stats summary of the same launch shapes is "
+                        "profiles/r1/bf16_b512_v6_kernel_stats.csv (bench.py --streams 1: 115.0 us average over the family)",
             "per_kernel_config": {names[i]: {"launches": ln[i], "ms": ms[i], "gflop": fl[i] / 1e9,
                                              "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] else 0.0}
                                   for i in range(8) if ln[i]},
