@@ -50,8 +50,11 @@ def conv_raw(x2d, w_nck, bias, kind, B, Lin, act=0, slope=0.0, res=None):
     y = _empty(B * Lout, ldc)
     bp = None
     if bias is not None:
-        bp = _zeros(Np)
-        bp[:N] = bias
+        if Np == N and bias.is_contiguous() and bias.dtype == torch.float32:
+            bp = bias                       # no padding to add: skips a fill and a copy launch per Linear
+        else:
+            bp = _zeros(Np)
+            bp[:N] = bias
     check(L.pt_conv1d_cl(ptr(x2d), x2d.shape[1], ptr(wp), ptr(bp), N, Np, Kp, kind, B, Lin, ptr(y), ldc, act, slope,
                          ptr(res), 0 if res is None else res.shape[1], stream()))
     return y, Lout
