@@ -149,8 +149,8 @@ int pt_gemm_bf16_addln(const void* A, int lda, const void* W, const float* bias,
 int pt_attention_cl(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,
                     int Nq, int Nk, int H, void* stream);
 /* the same core in the bf16 mode: Q/K/V/O are bf16 bit patterns (leading dims in elements, multiples of 8, 16-byte aligned
- * bases), bf16 MFMA with fp32 softmax statistics and accumulation; K and V of a (clip, head) stay resident in LDS, so
- * Nk <= 544. */
+ * bases), bf16 MFMA with fp32 softmax statistics and accumulation; K and V of a (clip, head) stay resident in LDS up to
+ * 544 keys and stream through it in 256-key chunks beyond (any Nk). */
 int pt_attention_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int B,
                       int Nq, int Nk, int H, void* stream);
 /* measurement aid (bench.py roofline leg): when enabled every tap-GEMM launch is bracketed by HIP events

@@ -8,7 +8,9 @@ from probtalk_amd import _lib
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,Nq,Nk", [(3, 148, 148), (2, 148, 37), (2, 300, 300), (1, 50, 7), (2, 33, 160), (1, 1, 1)])
+@pytest.mark.parametrize("B,Nq,Nk", [(3, 148, 148), (2, 148, 37), (2, 300, 300), (1, 50, 7), (2, 33, 160), (1, 1, 1),
+                                      # beyond the LDS-resident key range: K / V streamed in 256-key chunks
+                                      (2, 600, 600), (1, 700, 545), (1, 40, 1000), (1, 1800, 1800)])
 def test_attention_bf16_matches_float64(B, Nq, Nk):
     L, H = _lib.lib(), 8
     g = torch.Generator().manual_seed(B * 1000 + Nq + Nk)

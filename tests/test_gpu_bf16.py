@@ -133,3 +133,18 @@ def test_condition_encoders_bf16():
     mask[:, :, :30] = 1
     cond = pn.condition(mm.cuda() * mask.cuda(), mask.cuda(), ref_audio.cuda())
     check_bf16(cond.cpu(), O.predictor_condition(sd_p, mm * mask, mask, ref_audio), "motion-context encoder T=300")
+
+
+def test_refiner_bf16_long_sequence():
+    """600 frames: beyond the bf16 attention's LDS-resident key range (544), K / V stream through LDS in chunks."""
+    from probtalk_amd.nets.transformer_modules import RTransformer
+    rt = RTransformer(376, 768, 512, 6, use_label=True, motion_context=True).eval()
+    rt.load_state_dict(ref_state_dict("HFTransformer"))
+    rt.set_precision("bf16")
+    sd = ref_state_dict("HFTransformer")
+    B, T = 1, 600
+    x, a = make_input("ref.x600", (B, 376, T)), make_input("ref.a600", (B, 768, T))
+    m = torch.zeros(B, 1, T)
+    m[:, :, 200:260] = 1
+    lab = torch.tensor([2])
+    check_bf16(rt(x.cuda(), a.cuda(), m.cuda(), lab.cuda()).cpu(), O.rtransformer(sd, x, a, m, lab), "refiner T=600")
