@@ -1070,8 +1070,24 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
                                                       unsigned long long seed) {
   const float keep_scale = 1.f / (1.f - p);
   const unsigned thr = (unsigned)((double)p * 4294967296.0);
+  const unsigned long long base = seed * 0x100000001B3ull;
+  if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
+    // four elements per lane and 16-byte accesses; the mask stays a function of (seed, element index), so any mix of
+    // this path and the scalar tail replays the same mask
+    const size_t n4 = n >> 2;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n4; v += (size_t)gridDim.x * 256) {
+      const f32x4 in = *reinterpret_cast<const f32x4*>(x + 4 * v);
+      f32x4 out;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out[i] = mix32(base + 4 * v + i) >= thr ? in[i] * keep_scale : 0.f;
+      *reinterpret_cast<f32x4*>(y + 4 * v) = out;
+    }
+    for (size_t e = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256)
+      y[e] = mix32(base + e) >= thr ? x[e] * keep_scale : 0.f;
+    return;
+  }
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256)
-    y[e] = mix32(seed * 0x100000001B3ull + e) >= thr ? x[e] * keep_scale : 0.f;
+    y[e] = mix32(base + e) >= thr ? x[e] * keep_scale : 0.f;
 }
 int launch_dropout(const float* x, float* y, size_t n, float p, unsigned long long seed, hipStream_t s) {
   PT_CHECK(x && y && n > 0 && p >= 0.f && p < 1.f, "dropout: bad argument");
