@@ -148,3 +148,27 @@ def test_refiner_bf16_long_sequence():
     m[:, :, 200:260] = 1
     lab = torch.tensor([2])
     check_bf16(rt(x.cuda(), a.cuda(), m.cuda(), lab.cuda()).cpu(), O.rtransformer(sd, x, a, m, lab), "refiner T=600")
+
+
+def test_bf16_large_row_kernels_end_to_end():
+    """More than 2,048 rows per Linear: the wide Linears take gemm8_kernel and the row kernel its tall tiles (smaller
+    batches route to the 4-wave kernel / short tiles), checked end to end against the oracle."""
+    sd = ref_state_dict("Predictor")
+    pn = _predictor()
+    B, Tq = 16, 37                                                   # 16 x 148 = 2,368 token rows
+    cond = make_input("bf.cond16", (B, 768, Tq))
+    ids = make_input("bf.ids16", (B, Tq, 4), "int", low=0, high=129)
+    lab = torch.arange(B) % 4
+    out = pn.decoder.tokens_to_logits(ids.cuda(), lab.cuda(), cond.cuda())
+    check_bf16(out.cpu(), O.tokens_to_logits(sd, ids, lab, cond), "predictor logits, 2,368 rows")
+    from probtalk_amd.nets.transformer_modules import RTransformer
+    rt = RTransformer(376, 768, 512, 6, use_label=True, motion_context=True).eval()
+    rt.load_state_dict(ref_state_dict("HFTransformer"))
+    rt.set_precision("bf16")
+    sdr = ref_state_dict("HFTransformer")
+    B, T = 8, 300                                                    # 2,400 frame rows
+    x, a = make_input("ref.x8", (B, 376, T)), make_input("ref.a8", (B, 768, T))
+    m = torch.zeros(B, 1, T)
+    m[:, :, 40:90] = 1
+    lab = torch.arange(B) % 4
+    check_bf16(rt(x.cuda(), a.cuda(), m.cuda(), lab.cuda()).cpu(), O.rtransformer(sdr, x, a, m, lab), "refiner, 2,400 rows")
