@@ -100,6 +100,10 @@ int pt_predictor_sample_seed_dev(pt_model* m, const int64_t* label, const float*
 /* The noise pt_predictor_sample_seeded uses in pass `step`, written out: noise_q (B,N,V), noise_g (B,N).  Feeding these to
  * pt_predictor_sample reproduces the seeded codes (test hook; also a stand-alone Exp(1) / Gumbel generator). */
 int pt_maskgit_noise(unsigned long long seed, int step, int B, int N, int V, float* noise_q, float* noise_g, void* stream);
+/* The generator's last stage on caller-chosen 23-bit patterns: u = (bits + 0.5) / 2^23 in [2^-24, 1 - 2^-24], noise_q =
+ * -log u, noise_g = -log(-log u), n values each (test hook: the extremes of the range must stay finite; torch's Gumbel
+ * likewise clamps its uniform away from 0 and 1, PTransformer.py:697-698). */
+int pt_maskgit_noise_from_bits(const uint32_t* bits, int n, float* u, float* noise_q, float* noise_g, void* stream);
 
 /* ---- refiner ------------------------------------------------------------------------------ */
 size_t pt_refiner_workspace_bytes(const pt_model* m, int B, int T);

@@ -44,6 +44,7 @@ def _proto(lib):
     lib.pt_predictor_sample_seeded.argtypes = [vp, vp, vp, C.c_uint64, i, i, i, vp, vp, vp, sz, vp]
     lib.pt_predictor_sample_seed_dev.argtypes = [vp, vp, vp, vp, i, i, i, vp, vp, vp, sz, vp]
     lib.pt_maskgit_noise.argtypes = [C.c_uint64, i, i, i, i, vp, vp, vp]
+    lib.pt_maskgit_noise_from_bits.argtypes = [vp, i, vp, vp, vp, vp]
     lib.pt_refiner_forward.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp, vp, sz, vp]
     lib.pt_interp_blend.argtypes = [vp, i, i, i, i, vp, vp, i, vp, vp]
     lib.pt_conv1d_cl.argtypes = [vp, i, vp, vp, i, i, i, i, i, i, vp, i, i, f, vp, i, vp]
@@ -98,7 +99,7 @@ EXPORTS = [
     "pt_model_set_precision",
     "pt_vqvae_workspace_bytes", "pt_vqvae_encode", "pt_vqvae_decode", "pt_vqvae_decode_codes", "pt_pq_quantize",
     "pt_pq_quantize_all", "pt_cond_encoder_workspace_bytes", "pt_cond_encoder_forward",
-    "pt_predictor_workspace_bytes", "pt_predictor_condition", "pt_predictor_logits", "pt_predictor_sample", "pt_predictor_sample_seeded", "pt_predictor_sample_seed_dev", "pt_maskgit_noise",
+    "pt_predictor_workspace_bytes", "pt_predictor_condition", "pt_predictor_logits", "pt_predictor_sample", "pt_predictor_sample_seeded", "pt_predictor_sample_seed_dev", "pt_maskgit_noise", "pt_maskgit_noise_from_bits",
     "pt_refiner_workspace_bytes", "pt_refiner_forward", "pt_interp_blend", "pt_conv1d_cl", "pt_ncl_to_cl",
     "pt_cl_to_ncl", "pt_pq_search_cl", "pt_pq_gather_cl", "pt_attention_cl", "pt_attention_bf16", "pt_gemm_bf16", "pt_gemm_bf16_lnmod",
     "pt_gemm_bf16_addln", "pt_prof_enable",

@@ -34,6 +34,7 @@ int launch_clip_coef(const float* sumsq, float max_norm, float* coef, float* nor
 int launch_add(const float* a, const float* b, float* out, size_t n, hipStream_t s);
 int launch_attention_bf16(const unsigned short* Q, int ldq, const unsigned short* K, int ldk, const unsigned short* V, int ldv, unsigned short* O, int ldo, int B, int Nq, int Nk, int H, hipStream_t s);
 int launch_maskgit_noise(unsigned long long seed, int step, int B, int N, int V, float* q, float* g, hipStream_t s);
+int launch_maskgit_bits(const unsigned* bits, int n, float* u, float* q, float* g, hipStream_t s);
 int launch_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw, float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, hipStream_t s, int reseed);
 int launch_vq_losses(const float* pred, int ldp, const float* gt, int ldg, int B, int T, int nparts, const int* bounds, const float* weights, int vel_cols, float beta, float* sums, float* dpred, int lddp, hipStream_t s, const float* nmask, float t_nmask, int l1);
 int launch_sqdiff(const float* a, const float* b, size_t n, float* out, hipStream_t s);
@@ -190,6 +191,9 @@ int pt_predictor_sample_seed_dev(pt_model* h, const int64_t* label, const float*
 }
 int pt_maskgit_noise(unsigned long long seed, int step, int B, int N, int V, float* noise_q, float* noise_g, void* stream) {
   return launch_maskgit_noise(seed, step, B, N, V, noise_q, noise_g, (hipStream_t)stream);
+}
+int pt_maskgit_noise_from_bits(const uint32_t* bits, int n, float* u, float* noise_q, float* noise_g, void* stream) {
+  return launch_maskgit_bits(bits, n, u, noise_q, noise_g, (hipStream_t)stream);
 }
 size_t pt_refiner_workspace_bytes(const pt_model* h, int B, int T) {
   if (!h || !h->m.finalized) return 0;

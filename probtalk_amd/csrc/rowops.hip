@@ -180,14 +180,19 @@ int launch_mask_onehot(const float* mask, float* cond, int rows, int ld, int c0,
 //   re-mask every token whose confidence is below the mask_len-th smallest.
 // ---------------------------------------------------------------------------
 // Counter-based noise of the sampler's default mode (no noise tensors in HBM): element idx of stream `stream` under `seed`
-// -> uniform in (0,1) with 24 random bits (splitmix64 finaliser of a Weyl sequence); the categorical draw uses
+// -> uniform in (0,1) with 23 random bits (splitmix64 finaliser of a Weyl sequence); the categorical draw uses
 // q = -log u ~ Exp(1), the confidence uses g = -log(-log u) ~ Gumbel(0,1).
+// k + 0.5 with k < 2^23 is exact in fp32 (24 significant bits), so u lies in [2^-24, 1 - 2^-24]: never 0 and never 1
+// (with 24 bits k = 2^24 - 1 rounded to 2^24 and gave u = 1, a Gumbel draw of +inf and, at temp = 0, a NaN confidence).
+__device__ __forceinline__ float mg_bits_to_uniform(unsigned k23) {
+  return ((float)(k23 & 0x7FFFFFu) + 0.5f) * (1.0f / 8388608.0f);
+}
 __device__ __forceinline__ float mg_uniform(unsigned long long seed, unsigned long long stream, unsigned long long idx) {
   unsigned long long z = idx * 0x9E3779B97F4A7C15ull + seed * 0xD1B54A32D192ED03ull + stream * 0x8CB92BA72F3D8DD7ull;
   z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
   z ^= z >> 27; z *= 0x94D049BB133111EBull;
   z ^= z >> 31;
-  return ((float)(unsigned)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);
+  return mg_bits_to_uniform((unsigned)(z >> 41));
 }
 __device__ __forceinline__ float mg_exp1(unsigned long long seed, int step, unsigned long long e) {
   return -logf(mg_uniform(seed, 2ull * step, e));
@@ -202,6 +207,21 @@ __global__ void maskgit_noise_kernel(unsigned long long seed, int step, size_t n
     q[e] = mg_exp1(seed, step, e);
     if (e < ng) g[e] = mg_gumbel(seed, step, e);
   }
+}
+// test hook: the bits -> (u, Exp(1), Gumbel) mapping of the generator on caller-chosen bit patterns (extremes of the range)
+__global__ void maskgit_bits_kernel(const unsigned* __restrict__ bits, int n, float* __restrict__ u, float* __restrict__ q,
+                                    float* __restrict__ g) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = mg_bits_to_uniform(bits[i]);
+  u[i] = v;
+  q[i] = -logf(v);
+  g[i] = -logf(-logf(v));
+}
+int launch_maskgit_bits(const unsigned* bits, int n, float* u, float* q, float* g, hipStream_t s) {
+  PT_CHECK(bits && u && q && g && n > 0, "maskgit_bits: bad argument");
+  PT_LAUNCH(maskgit_bits_kernel, dim3((n + 255) / 256), dim3(256), 0, s, bits, n, u, q, g);
+  return 0;
 }
 int launch_maskgit_noise(unsigned long long seed, int step, int B, int N, int V, float* q, float* g, hipStream_t s) {
   PT_CHECK(B > 0 && N > 0 && V > 0 && q && g, "maskgit_noise: bad argument");
@@ -253,7 +273,7 @@ __global__ __launch_bounds__(1024) void maskgit_step_kernel(const float* __restr
       const bool unk = cur == mask_id;
       samp[n] = unk ? besti : cur;
       const float gn = noise_g ? noise_g[(size_t)b * N + n] : mg_gumbel(seed, step, (size_t)b * N + n);
-      conf[n] = unk ? logf(bestp) + temp * gn : INFINITY;
+      conf[n] = unk ? (temp != 0.f ? logf(bestp) + temp * gn : logf(bestp)) : INFINITY;
       my_unknown += unk;
     }
   }

@@ -84,3 +84,41 @@ def test_default_call_follows_torch_manual_seed():
     torch.manual_seed(7)
     c = dec.sample_good(label, cond, None, T=8)
     assert torch.equal(a, c) and not torch.equal(a, b)
+
+
+def test_uniform_extremes_stay_inside_the_open_interval():
+    """The generator's bits -> uniform map at the ends of its 23-bit range (and beyond it: upper bits are masked off):
+    u never reaches 0 or 1, so Exp(1) > 0 and Gumbel are finite for every possible draw."""
+    pats = [0, 1, 2, (1 << 22) - 1, 1 << 22, (1 << 23) - 2, (1 << 23) - 1, (1 << 24) - 1, 0xFFFFFFFF, 1 << 23]
+    bits = torch.tensor(pats, dtype=torch.int64).to(torch.uint32).cuda() if hasattr(torch, "uint32") else None
+    if bits is None:
+        bits = torch.tensor([p - (1 << 32) if p >= (1 << 31) else p for p in pats], dtype=torch.int32).cuda()
+    n = len(pats)
+    u, q, g = (torch.empty(n, device="cuda") for _ in range(3))
+    _lib.check(_lib.lib().pt_maskgit_noise_from_bits(_lib.ptr(bits), n, _lib.ptr(u), _lib.ptr(q), _lib.ptr(g), _lib.stream()))
+    torch.cuda.synchronize()
+    ud = u.double().cpu()
+    expect = torch.tensor([((p & 0x7FFFFF) + 0.5) / 2.0 ** 23 for p in pats], dtype=torch.float64)
+    assert torch.equal(ud, expect)                                        # k + 0.5 is exact in fp32
+    assert float(ud.min()) == 2.0 ** -24 and float(ud.max()) == 1 - 2.0 ** -24
+    assert bool(torch.isfinite(q).all()) and float(q.min()) > 0
+    assert bool(torch.isfinite(g).all())
+
+
+def test_last_pass_ignores_the_gumbel_draw():
+    """temp = 4.5 * (1 - ratio) is 0 in the last pass (PTransformer.py:624-627): an infinite injected Gumbel value must not
+    turn the confidence into NaN and leave mask ids in the output."""
+    from probtalk_amd.weights import make_input
+    dec = _predictor()
+    B, Tq, T = 2, 11, 8
+    N, V = Tq * 4, 128
+    cond = make_input("seeded.cond3", (B, 768, Tq)).cuda()
+    label = torch.tensor([1, 2]).cuda()
+    qs, gs = zip(*[_noise(99, s, B, N, V) for s in range(T)])
+    gs = torch.stack(gs)
+    ref = dec.sample_good(label, cond, None, T=T, noise=(torch.stack(qs), gs))
+    gs2 = gs.clone()
+    gs2[T - 1] = float("inf")
+    out = dec.sample_good(label, cond, None, T=T, noise=(torch.stack(qs), gs2))
+    assert int(out.min()) >= 0 and int(out.max()) < V
+    assert torch.equal(out, ref)
