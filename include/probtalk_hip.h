@@ -61,6 +61,13 @@ int pt_vqvae_decode_codes(pt_model* m, const void* codes, int codes_are_int64, i
 /* ProductQuantization.forward eval on a caller-supplied latent: z (B,emb,W) -> quantized (B,emb,W), indices (B,W,G). */
 int pt_pq_quantize(pt_model* m, const float* z, int B, int W, float* quantized, int64_t* indices, void* ws,
                    size_t ws_bytes, void* stream);
+/* pt_pq_quantize for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc): no counterpart in the reference.  Same inputs, outputs and results as pt_pq_quantize,
+ * but the two channels-last staging images live in a 16 MiB device array that is part of the library image (one copy per
+ * GPU, held until the process ends) instead of a caller workspace; the call allocates nothing.  Limit: B*W <= 4096 latent
+ * rows and emb_dim <= 512, otherwise it returns non-zero with a message naming the limit.  Every call on one GPU uses that
+ * GPU's array: calls that overlap on one GPU (two streams, two threads) race; calls on one stream are safe. */
+int pt_pq_quantize_static(pt_model* m, const float* z, int B, int W, float* quantized, int64_t* indices, void* stream);
 /* ProductQuantization.quantize_all (vqvae_modules.py:557-564): idx (rows,G) -> out (rows, emb) row-major. */
 int pt_pq_quantize_all(pt_model* m, const void* idx, int idx_are_int64, int rows, float* out, void* stream);
 

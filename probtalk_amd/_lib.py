@@ -36,6 +36,7 @@ def _proto(lib):
     lib.pt_vqvae_decode.argtypes = [vp, vp, i, i, vp, vp, sz, vp]
     lib.pt_vqvae_decode_codes.argtypes = [vp, vp, i, i, i, vp, vp, sz, vp]
     lib.pt_pq_quantize.argtypes = [vp, vp, i, i, vp, vp, vp, sz, vp]
+    lib.pt_pq_quantize_static.argtypes = [vp, vp, i, i, vp, vp, vp]
     lib.pt_pq_quantize_all.argtypes = [vp, vp, i, i, vp, vp]
     lib.pt_cond_encoder_forward.argtypes = [vp, vp, i, i, vp, vp, sz, vp]
     lib.pt_predictor_condition.argtypes = [vp, vp, vp, vp, i, i, vp, vp, sz, vp]
@@ -97,7 +98,7 @@ def _proto(lib):
 EXPORTS = [
     "pt_last_error", "pt_version", "pt_model_create", "pt_model_set_tensor", "pt_model_finalize", "pt_model_destroy",
     "pt_model_set_precision",
-    "pt_vqvae_workspace_bytes", "pt_vqvae_encode", "pt_vqvae_decode", "pt_vqvae_decode_codes", "pt_pq_quantize",
+    "pt_vqvae_workspace_bytes", "pt_vqvae_encode", "pt_vqvae_decode", "pt_vqvae_decode_codes", "pt_pq_quantize", "pt_pq_quantize_static",
     "pt_pq_quantize_all", "pt_cond_encoder_workspace_bytes", "pt_cond_encoder_forward",
     "pt_predictor_workspace_bytes", "pt_predictor_condition", "pt_predictor_logits", "pt_predictor_sample", "pt_predictor_sample_seeded", "pt_predictor_sample_seed_dev", "pt_maskgit_noise", "pt_maskgit_noise_from_bits",
     "pt_refiner_workspace_bytes", "pt_refiner_forward", "pt_interp_blend", "pt_conv1d_cl", "pt_ncl_to_cl",

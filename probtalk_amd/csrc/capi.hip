@@ -1,5 +1,6 @@
 // extern "C" surface of libprobtalk_hip.so (declarations: include/probtalk_hip.h).
 #include <cstring>
+#include <mutex>
 
 #include "../../include/probtalk_hip.h"
 #include "model.h"
@@ -42,6 +43,36 @@ int launch_commit_bwd(const float* dq, const float* z, const float* q, const flo
 int launch_embed_pe(const int* ids, const float* tok, const double* pe, const double* ppe, float* x, unsigned short* xb, int rows, int N, int G, int vocab, hipStream_t s);
 }  // namespace pt
 
+// ---- pt_pq_quantize for callers that cannot allocate: its two channels-last staging images (latent rows in, code rows
+// out) live in one file-scope device array instead of a caller workspace.  PT_PQ_STATIC_MAX_ROWS latent rows of up to
+// PT_PQ_STATIC_MAX_LD floats each, twice: 16 MiB per GPU, held until the process ends.
+#define PT_PQ_STATIC_MAX_ROWS 4096
+#define PT_PQ_STATIC_MAX_LD 512
+static __device__ __align__(256) unsigned char scratch[2ull * PT_PQ_STATIC_MAX_ROWS * PT_PQ_STATIC_MAX_LD * sizeof(float)];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices] = {};   // per device: the address of THAT device's copy of `scratch`
+
+// Device address of the current device's `scratch`, resolved once per device (the array's name is only a host-side
+// stand-in for the symbol; every GPU holds its own copy at its own address).
+int scratch_for_current_device(void** out) {
+  int dev = -1;
+  PT_HIP(hipGetDevice(&dev));
+  PT_CHECK(dev >= 0 && dev < kMaxDevices, "pt_pq_quantize_static: device ordinal %d out of range", dev);
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    PT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    PT_CHECK(p != nullptr, "pt_pq_quantize_static: hipGetSymbolAddress returned a null address on device %d", dev);
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return 0;
+}
+}  // namespace
+
 extern "C" {
 
 const char* pt_last_error(void) { return last_error(); }
@@ -59,6 +90,10 @@ pt_model* pt_model_create(const char* kind, const int* cfg, int ncfg) {
   if (hipGetDevice(&dev) != hipSuccess) {
     set_error("pt_model_create: no HIP device available");
     return nullptr;
+  }
+  if (strncmp(kind, "vqvae", 5) == 0) {   // set-up time: resolve this device's static scratch (pt_pq_quantize_static)
+    void* p = nullptr;
+    if (scratch_for_current_device(&p)) return nullptr;
   }
   pt_model* h = new pt_model();
   h->m.kind = kind;
@@ -129,6 +164,28 @@ int pt_pq_quantize(pt_model* h, const float* z, int B, int W, float* quantized, 
   float* z_cl = ar.f32((size_t)B * W * ld);
   float* q_cl = ar.f32((size_t)B * W * ld);
   PT_CHECK(!ar.overflow, "pt_pq_quantize: workspace too small (%zu given, %zu needed)", ws_bytes, ar.off);
+  if (launch_ncl_to_cl(z, z_cl, B, v.emb_dim, W, ld, 0, ld, s)) return 1;
+  if (launch_pq_search(z_cl, ld, v.codebooks, B * W, v.groups, v.emb_dim / v.groups, v.num_codes, indices,
+                       quantized ? q_cl : nullptr, ld, s)) return 1;
+  if (quantized && launch_cl_to_ncl(q_cl, ld, 0, quantized, B, v.emb_dim, W, s)) return 1;
+  return 0;
+}
+int pt_pq_quantize_static(pt_model* h, const float* z, int B, int W, float* quantized, int64_t* indices, void* stream) {
+  PT_CHECK(h && z && indices, "pt_pq_quantize_static: null argument");
+  PT_CHECK(h->m.finalized && (h->m.kind == "vqvae_sc" || h->m.kind == "vqvae_legacy"), "pt_pq_quantize_static: wrong model");
+  PT_CHECK(B > 0 && W > 0, "pt_pq_quantize_static: empty input B=%d W=%d", B, W);
+  const VQVAE& v = h->m.vq;
+  const int ld = ld_of(v.emb_dim);
+  const long long rows = (long long)B * W;
+  PT_CHECK(rows <= PT_PQ_STATIC_MAX_ROWS && ld <= PT_PQ_STATIC_MAX_LD,
+           "pt_pq_quantize_static: %lld latent rows of %d floats exceed the static scratch (at most %d rows of %d floats); "
+           "use pt_pq_quantize with a caller workspace", rows, ld, PT_PQ_STATIC_MAX_ROWS, PT_PQ_STATIC_MAX_LD);
+  void* base = nullptr;
+  if (scratch_for_current_device(&base)) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  // both images are written in full (all ld columns of every row) before they are read: nothing has to start at zero
+  float* z_cl = (float*)base;
+  float* q_cl = z_cl + (size_t)PT_PQ_STATIC_MAX_ROWS * PT_PQ_STATIC_MAX_LD;
   if (launch_ncl_to_cl(z, z_cl, B, v.emb_dim, W, ld, 0, ld, s)) return 1;
   if (launch_pq_search(z_cl, ld, v.codebooks, B * W, v.groups, v.emb_dim / v.groups, v.num_codes, indices,
                        quantized ? q_cl : nullptr, ld, s)) return 1;
