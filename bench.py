@@ -4,10 +4,14 @@
 Workload (BASELINE.json configs[3], the per-GPU share of the configuration the metric is quoted
 on): the full holistic pipeline  audio features -> AudEnc -> motion-context encoder -> 8-pass
 MaskGIT predictor -> PQ gather + conv decoder -> resize/blend -> refiner transformer -> blend,
-one micro-batch of 64 synthetic 300-frame clips per step, weights random-initialised with the
-reference's architecture (probtalk_amd.weights), inputs resident in HBM.
+one batch of 512 synthetic 300-frame clips per step per GPU (4096 clips over 8 GPUs), weights
+random-initialised with the reference's architecture (probtalk_amd.weights), inputs resident in HBM.
 
-    python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU over RCCL.  Under torch.distributed.run (WORLD_SIZE set) this process is one of the ranks;
+without it `--gpus N` makes this process the parent of N fresh rank processes (probtalk_amd/launch.py: started before
+anything here touches the GPU, watched with a wall-clock limit, all of them ended when one fails).
 
 Prints ONE JSON line on rank 0 (see the field notes in DESIGN.md §Measurement).
 """
@@ -29,7 +33,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak (
 MFLOP_PER_FRAME = 296.0          # full pipeline, algorithmic (2*MAC of the reference modules)
 
 
-def cpu_baseline(B=32, T=300, runs=3):
+def cpu_baseline(B=32, T=300, runs=5):
     """The CPU oracle ("port") on a bounded sample of the same workload, on this box's host cores."""
     from oracle import probtalk_oracle as O
     from probtalk_amd.weights import make_input
@@ -104,18 +108,75 @@ def train_bench(a, rank, world, dev):
         print(json.dumps(res), flush=True)
 
 
+def time_steps(step, fence, steps, warmup, world, dev):
+    """W untimed warm-up steps, then exactly K steps between two fences (barrier + device synchronize); max over ranks."""
+    import torch.distributed as dist
+    out = None
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return dt, out
+
+
+def gemm_roofline(pred, ref, inputs, dtype, ms_per_step, B, T):
+    """HIP-event timing of every GEMM launch of one extra, untimed step on one stream (pt_prof_enable/pt_prof_read)."""
+    from probtalk_amd import _lib
+    from probtalk_amd.synthetic import holistic_step
+    L = _lib.lib()
+    torch.cuda.synchronize()
+    _lib.check(L.pt_prof_enable(1))
+    holistic_step(pred, ref, *inputs, sync=False)
+    torch.cuda.synchronize()
+    ms, fl, ln = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int * 8)()
+    _lib.check(L.pt_prof_read(ms, fl, ln))
+    _lib.check(L.pt_prof_enable(0))
+    names = ("f32 128x128", "f32 64x128", "f32 64x64", "bf16 128x128", "bf16 64x128", "bf16 64x64",
+             "bf16 256x256 8-phase lds-dma (gemm8_kernel)", "bf16 160x512 row-complete +LN epilogues (gemm_row_kernel)")
+    dom = range(3, 8) if dtype == "bf16" else range(0, 3)     # the dominant kernel family of this mode
+    peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+    kname = "pt::gemm_row_kernel + pt::gemm8_kernel + pt::gemm_bf16_kernel (bf16 MFMA GEMMs of the transformers and conv stacks)" \
+        if dtype == "bf16" else "pt::gemm_f32_kernel (tap-GEMM, fp32 MFMA 32x32x2)"
+    tot_ms, tot_fl, tot_n = sum(ms[i] for i in dom), sum(fl[i] for i in dom), sum(ln[i] for i in dom)
+    ach = tot_fl / (tot_ms * 1e-3) / 1e12
+    step_tflop = MFLOP_PER_FRAME * 1e6 * B * T / 1e12
+    return {
+        "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+        "kernel": kname + ", all launches of one step",
+        "launches_per_step": tot_n, "avg_launch_ms": tot_ms / max(tot_n, 1),
+        "algorithmic_gflop_per_launch": tot_fl / max(tot_n, 1) / 1e9,
+        "kernel_ms_per_step": tot_ms,
+        "timed_as": "every launch of one untimed extra step on ONE stream at the full per-GPU batch, HIP events on the "
+                    "launch stream; rocprofv3 --kernel-trace --stats summaries of the same launch shapes are under profiles/",
+        "per_kernel_config": {names[i]: {"launches": ln[i], "ms": ms[i], "gflop": fl[i] / 1e9,
+                                         "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] else 0.0}
+                              for i in range(8) if ln[i]},
+        "whole_step": {"algorithmic_tflop": step_tflop, "achieved_tflops": step_tflop / (1e-3 * ms_per_step)},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", choices=("infer", "train"), default="infer",
                     help="infer (default): the metric's full pipeline; train: configs[4] predictor training step")
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks (one process per GPU). Without WORLD_SIZE in the environment and N > 1 this process spawns "
+                         "the N ranks itself; under torch.distributed.run it must equal WORLD_SIZE")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512,
                     help="clips per step per GPU: the per-GPU share of configs[3] (4096 clips over 8 GPUs), one batch")
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--dtype", choices=("bf16", "f32"), default="bf16",
-                    help="arithmetic of the predictor/refiner transformers (conv stacks and PQ stay fp32)")
+                    help="arithmetic of the predictor/refiner transformers (PQ-VAE encode and code search always fp32)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the step's clips are split over (contiguous shares, joined before the step returns); "
                          "1 = the whole batch as one launch sequence")
@@ -123,28 +184,42 @@ def main():
                     help="replay the step from one captured HIP graph (probtalk_amd/graphs.py): for small, launch-bound batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-arithmetic leg of the default bf16 run")
     a = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and (a.gpus or 1) > 1:
+        # parent of the ranks: nothing in this process has touched (or will touch) the GPU
+        from probtalk_amd.launch import spawn_ranks
+        limit = float(os.environ.get("PT_BENCH_LAUNCH_LIMIT", "1500"))
+        sys.exit(spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], a.gpus, limit))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus is not None and a.gpus != world:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N` (spawns its own "
+                 f"ranks) or under torch.distributed.run with --nproc-per-node equal to --gpus")
+    if os.environ.get("PT_BENCH_FAIL_RANK") == str(rank) and world > 1:       # launcher failure-path test hook
+        sys.exit(1)
     backend = os.environ.get("PT_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of the N > 1 control flow on one GPU
     if backend == "gloo":
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        import datetime
         import torch.distributed as dist
+        # a stuck collective ends the job instead of hanging it (RCCL's watchdog aborts after `timeout`)
+        tmo = datetime.timedelta(seconds=float(os.environ.get("PT_BENCH_COLLECTIVE_TIMEOUT", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)      # RCCL over xGMI
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
     if a.workload == "train":
         train_bench(a, rank, world, dev)
         if world > 1:
             dist.destroy_process_group()
         return
-    from probtalk_amd import _lib
     from probtalk_amd.dist import OutputGatherer
     from probtalk_amd.synthetic import build_pipeline, holistic_step
 
@@ -168,9 +243,14 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(a.streams)] if a.streams > 1 and not a.graph else None
 
     def step():
-        out = graphed(aud, gt, mask, ids) if graphed else holistic_step(pred, ref, aud, gt, mask, ids, sync=False, streams=streams)
+        if graphed:
+            if gather is not None:
+                gather.wait()       # the replay overwrites the graph's static output: the previous gather must have read it
+            out = graphed(aud, gt, mask, ids)
+        else:
+            out = holistic_step(pred, ref, aud, gt, mask, ids, sync=False, streams=streams)
         if gather is not None:
-            gather.submit(out)          # RCCL all_gather of the outputs on a side stream, overlapped with the next step
+            gather.submit(out)          # RCCL gather of the outputs to rank 0 on a side stream, overlapped with the next step
         return out
 
     def fence():
@@ -180,78 +260,52 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt, out = time_steps(step, fence, a.steps, a.warmup, world, dev)
     assert bool(torch.isfinite(out).all()), "non-finite output"
     frames = world * B * T * a.steps
+    arith = {"bf16": "bf16 MFMA operands / fp32 accumulate in the transformers, condition encoders and PQ-VAE decoder", "f32": "fp32"}
     res = {
         "metric": "generated motion frames/sec (PQ-VAE+predictor+refiner)",
         "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": "configs[3] per-GPU share: full holistic pipeline (AudEnc + motion-context encoder + "
-                               "8-pass MaskGIT predictor + PQ gather/decode + refiner); "
-                               + ("bf16 MFMA operands / fp32 accumulate in the transformers, condition encoders and PQ-VAE decoder" if a.dtype == "bf16" else "fp32"),
+                               "8-pass MaskGIT predictor + PQ gather/decode + refiner); " + arith[a.dtype],
                    "clips_per_step_per_gpu": B, "frames_per_clip": T, "launch": "hip graph replay" if a.graph else (f"eager, clips split over {a.streams} HIP streams" if streams else "eager, one stream"),
-                   "parallelism": f"dp{world}: clips sharded over ranks, outputs all_gathered over RCCL"},
+                   "parallelism": f"dp{world}: clips sharded over ranks, outputs gathered to rank 0 over RCCL"},
     }
 
     if rank == 0 and not a.no_roofline:
-        L = _lib.lib()
-        torch.cuda.synchronize()
-        _lib.check(L.pt_prof_enable(1))
-        holistic_step(pred, ref, aud, gt, mask, ids, sync=False)
-        torch.cuda.synchronize()
-        ms, fl, ln = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int * 8)()
-        _lib.check(L.pt_prof_read(ms, fl, ln))
-        _lib.check(L.pt_prof_enable(0))
-        names = ("f32 128x128", "f32 64x128", "f32 64x64", "bf16 128x128", "bf16 64x128", "bf16 64x64",
-                 "bf16 256x256 8-phase lds-dma (gemm8_kernel)", "bf16 160x512 row-complete +LN epilogues (gemm_row_kernel)")
-        dom = range(3, 8) if a.dtype == "bf16" else range(0, 3)     # the dominant kernel family of this mode
-        peak = PEAK_BF16_MFMA_TFLOPS if a.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-        kname = "pt::gemm_row_kernel + pt::gemm8_kernel + pt::gemm_bf16_kernel (bf16 MFMA GEMMs of the transformers and conv stacks)" if a.dtype == "bf16" else \
-            "pt::gemm_f32_kernel (tap-GEMM, fp32 MFMA 32x32x2)"
-        tot_ms, tot_fl, tot_n = sum(ms[i] for i in dom), sum(fl[i] for i in dom), sum(ln[i] for i in dom)
-        ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        step_tflop = MFLOP_PER_FRAME * 1e6 * B * T / 1e12
-        res["roofline"] = {
-            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-            "kernel": kname + ", all launches of one step",
-            "launches_per_step": tot_n, "avg_launch_ms": tot_ms / max(tot_n, 1),
-            "algorithmic_gflop_per_launch": tot_fl / max(tot_n, 1) / 1e9,
-            "kernel_ms_per_step": tot_ms,
-            "timed_as": "every launch of one untimed extra step on ONE stream at the full per-GPU batch, HIP events on the "
-                        "launch stream; the rocprofv3 --kernel-trace --stats summary of the same launch shapes is "
-                        "profiles/r1/bf16_b512_v6_kernel_stats.csv (bench.py --streams 1: 115.0 us average over the family)",
-            "per_kernel_config": {names[i]: {"launches": ln[i], "ms": ms[i], "gflop": fl[i] / 1e9,
-                                             "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] else 0.0}
-                                  for i in range(8) if ln[i]},
-            "whole_step": {"algorithmic_tflop": step_tflop,
-                           "achieved_tflops": step_tflop / (1e-3 * res["ms_per_step"])},
-        }
+        res["roofline"] = gemm_roofline(pred, ref, (aud, gt, mask, ids), a.dtype, res["ms_per_step"], B, T)
         # HBM traffic of the same kernels from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
         # this process): launch-weighted mean bytes per launch, FETCH_SIZE doubled as the microarch guide prescribes
-        pmc_path = os.path.join(ROOT, "profiles", "r1", "bf16_pmc_summary.json")
-        if a.dtype == "bf16" and os.path.exists(pmc_path):
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", r, "bf16_pmc_summary.json") for r in ("r2", "r1"))
+                         if os.path.exists(q)), None)
+        if a.dtype == "bf16" and pmc_path:
             with open(pmc_path) as f:
                 pk = json.load(f)["kernels"]
-            fam = {k: v for k, v in pk.items() if any(t in k for t in ("gemm_row_kernel", "gemm8_kernel", "gemm_big_kernel", "gemm_bf16_kernel"))}
+            fam = {k: v for k, v in pk.items() if any(t in k for t in ("gemm_row_kernel", "gemm8_kernel", "gemm_big_kernel", "gemm_bf16_kernel", "sublayer_kernel", "conv_bf16_kernel"))}
             n = sum(v["launches"] for v in fam.values())
             if n:
                 res["roofline"]["traffic"] = sum(v["launches"] * v["hbm_bytes_per_launch"] for v in fam.values()) / n
-                res["roofline"]["traffic_unit"] = "bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r1/bf16_pmc_summary.json)"
+                res["roofline"]["traffic_unit"] = f"bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, {os.path.relpath(pmc_path, ROOT)})"
                 res["roofline"]["mfma_util_pmc"] = {k.split("pt::")[-1]: round(v["mfma_util"], 4) for k, v in fam.items()
                                                     if v.get("mfma_util") is not None}
+    if rank == 0 and world == 1 and a.dtype == "bf16" and not a.no_fp32 and not a.graph:
+        # the reference's own arithmetic (fp32, the 1e-4 parity path) on the same workload, a few steps
+        del pred, ref
+        torch.cuda.empty_cache()
+        pred32, ref32 = build_pipeline(seed=0)
+        k32 = max(2, min(3, a.steps))
+        dt32, out32 = time_steps(lambda: holistic_step(pred32, ref32, aud, gt, mask, ids, sync=False, streams=streams),
+                                 torch.cuda.synchronize, k32, 1, 1, dev)
+        assert bool(torch.isfinite(out32).all()), "non-finite fp32 output"
+        res["fp32"] = {"value": B * T * k32 / dt32, "unit": "frames/s", "steps": k32, "warmup": 1, "ms_per_step": 1e3 * dt32 / k32,
+                       "dtype": "f32", "note": "same workload with fp32 MFMA everywhere (pt_model_set_precision 0)"}
+        if not a.no_roofline:
+            r32 = gemm_roofline(pred32, ref32, (aud, gt, mask, ids), "f32", res["fp32"]["ms_per_step"], B, T)
+            res["fp32"]["roofline"] = {k: r32[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "launches_per_step",
+                                                           "kernel_ms_per_step", "whole_step")}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()
     if rank == 0:

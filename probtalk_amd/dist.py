@@ -23,50 +23,71 @@ def shard_batch(t, rank=None, world=None, dim=0):
 
 
 def gather_batch(t, n_total=None):
-    """Inverse of shard_batch along dim 0 on every rank (ragged last shards allowed)."""
+    """Inverse of shard_batch along dim 0 on every rank.  Ragged shards (n_total not a multiple of the world size) are
+    allowed; without n_total the per-rank lengths are exchanged first, so ranks holding q and q+1 items agree on the
+    sizes (deriving n_total from the local length would not)."""
     world = dist.get_world_size()
     if world == 1:
         return t
-    n_total = n_total if n_total is not None else t.shape[0] * world
-    sizes = [shard_range(n_total, r, world) for r in range(world)]
-    mx = max(hi - lo for lo, hi in sizes)
+    if n_total is None:
+        lens = torch.zeros(world, dtype=torch.int64, device=t.device if dist.get_backend() != "gloo" else "cpu")
+        lens[dist.get_rank()] = t.shape[0]
+        dist.all_reduce(lens)
+        sizes = [int(v) for v in lens.tolist()]
+    else:
+        sizes = [hi - lo for lo, hi in (shard_range(n_total, r, world) for r in range(world))]
+        if sizes[dist.get_rank()] != t.shape[0]:
+            raise ValueError(f"gather_batch: rank {dist.get_rank()} holds {t.shape[0]} items, its share of {n_total} is "
+                             f"{sizes[dist.get_rank()]}")
+    mx = max(sizes)
     pad = t
     if t.shape[0] < mx:
         pad = torch.cat([t, t.new_zeros((mx - t.shape[0],) + tuple(t.shape[1:]))])
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad.contiguous())
-    return torch.cat([b[:hi - lo] for b, (lo, hi) in zip(bufs, sizes)])
+    return torch.cat([b[:n] for b, n in zip(bufs, sizes)])
 
 
 class OutputGatherer:
-    """all_gather of equal-sized per-rank outputs on a side stream so it overlaps the next step's compute
-    (bucket = one step's output, 28.9 MB per rank at 64 x 376 x 300 fp32: large enough to run xGMI
-    point-to-point links at rate, small enough to hide behind a ~60 ms step)."""
+    """Gather of equal-sized per-rank outputs to rank `dst` on a side stream, so it overlaps the next step's compute.
 
-    def __init__(self, world, shape, device):
-        self.world = world
+    north_star asks for a gather, not an all-gather: only rank 0 needs the 4096 x 376 x 300 fp32 result (1.85 GB at
+    configs[3]).  Each peer sends its 231 MB once over its own point-to-point xGMI link to rank 0 (7 links in parallel,
+    ~1.5 ms at 153 GB/s per link); an all_gather would move 8x the bytes over the fabric and hold 2 x 1.85 GB of buffers
+    on every rank.  Only `dst` allocates the double-buffered result."""
+
+    def __init__(self, world, shape, device, dst=0):
+        self.world, self.dst = world, dst
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.cuda = torch.device(device).type == "cuda"
-        self.bufs = [torch.empty((world * shape[0],) + tuple(shape[1:]), device=device) for _ in range(2)]
+        self.bufs = [torch.empty((world * shape[0],) + tuple(shape[1:]), device=device) for _ in range(2)] \
+            if self.rank == dst else [None, None]
         self.i = 0
         self.stream = torch.cuda.Stream(device=device) if self.cuda else None
 
+    def _gather(self, out, buf):
+        host = self.cuda and dist.get_backend() == "gloo"       # rehearsal on one GPU: gloo gets host copies
+        src = out.cpu() if host else out.contiguous()
+        if self.rank == self.dst:
+            parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(self.world)] if host else list(buf.chunk(self.world))
+            dist.gather(src, parts, dst=self.dst)
+            if host:
+                buf.copy_(torch.cat(parts))
+        else:
+            dist.gather(src, None, dst=self.dst)
+
     def submit(self, out):
+        """Start gathering `out`; returns the destination buffer on rank dst (valid after wait()), None elsewhere."""
         buf = self.bufs[self.i % 2]
         self.i += 1
         if not self.cuda:
-            dist.all_gather_into_tensor(buf, out.contiguous()) if dist.get_backend() != "gloo" else \
-                dist.all_gather(list(buf.chunk(self.world)), out.contiguous())
+            self._gather(out, buf)
             return buf
         ev = torch.cuda.Event()
         ev.record()
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ev)
-            if dist.get_backend() == "gloo":            # rehearsal on one GPU: gloo gets host copies (see GradientReducer)
-                parts = [torch.empty(out.shape, dtype=out.dtype) for _ in range(self.world)]
-                dist.all_gather(parts, out.cpu())
-                buf.copy_(torch.cat(parts))
-            else:
-                dist.all_gather_into_tensor(buf, out)
+            self._gather(out, buf)
         out.record_stream(self.stream)
         return buf
 

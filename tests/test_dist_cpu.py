@@ -38,11 +38,17 @@ def _worker(rank, world, port, n_clips):
         out = mine * 2 + 1                      # stand-in for the per-rank pipeline
         back = gather_batch(out, n_total=n_clips)
         assert torch.equal(back, full * 2 + 1)
+        back = gather_batch(out)                # ragged shards without n_total: lengths are exchanged first
+        assert torch.equal(back, full * 2 + 1)
         if n_clips % world == 0:
-            g = OutputGatherer(world, tuple(out.shape), "cpu")
-            got = g.submit(out)
-            g.wait()
-            assert torch.equal(got, full * 2 + 1)
+            g = OutputGatherer(world, tuple(out.shape), "cpu")      # gather to rank 0 only
+            for rep in range(3):                                    # double-buffered: three steps reuse buffer 0
+                got = g.submit(out + rep)
+                g.wait()
+                if rank == 0:
+                    assert torch.equal(got, full * 2 + 1 + rep) and got is g.last()
+                else:
+                    assert got is None
     finally:
         dist.destroy_process_group()
 
@@ -134,3 +140,62 @@ def _overlap_worker(rank, world, port):
 
 def test_gradient_reducer_overlaps_backward_world2():
     mp.spawn(_overlap_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+# ---- bench.py's own launcher (probtalk_amd/launch.py): `bench.py --gpus N` without torchrun
+def _child_script(tmp_path, body):
+    p = tmp_path / "child.py"
+    p.write_text("import os, sys, time\nrank = int(os.environ['RANK'])\n" + body)
+    return [os.sys.executable, str(p)]
+
+
+def test_launcher_all_ranks_ok(tmp_path):
+    from probtalk_amd.launch import spawn_ranks
+    cmd = _child_script(tmp_path, "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                                  "open(os.path.join(os.path.dirname(__file__), f'ok{rank}'), 'w').write(os.environ['MASTER_PORT'])\n")
+    assert spawn_ranks(cmd, 3, 30) == 0
+    ports = {(tmp_path / f"ok{r}").read_text() for r in range(3)}
+    assert len(ports) == 1
+
+
+def test_launcher_failing_rank_stops_the_job(tmp_path):
+    """A rank that exits 1 while the others sit in a (here: simulated) collective: the parent kills them and returns
+    non-zero well within the limit."""
+    import time
+    from probtalk_amd.launch import spawn_ranks
+    cmd = _child_script(tmp_path, "open(os.path.join(os.path.dirname(__file__), f'pid{rank}'), 'w').write(str(os.getpid()))\n"
+                                  "if rank == 1:\n    time.sleep(0.5); sys.exit(1)\ntime.sleep(120)\n")
+    t0 = time.monotonic()
+    rc = spawn_ranks(cmd, 2, 60)
+    assert rc == 1 and time.monotonic() - t0 < 20
+    pid0 = int((tmp_path / "pid0").read_text())
+    try:
+        os.kill(pid0, 0)
+        alive = True
+    except OSError:
+        alive = False
+    assert not alive, "rank 0 was left running"
+
+
+def test_launcher_wall_clock_limit(tmp_path):
+    import time
+    from probtalk_amd.launch import spawn_ranks
+    cmd = _child_script(tmp_path, "time.sleep(120)\n")
+    t0 = time.monotonic()
+    assert spawn_ranks(cmd, 2, 1.5) == 124
+    assert time.monotonic() - t0 < 15
+
+
+def test_bench_parent_exits_nonzero_when_a_rank_fails():
+    """`bench.py --gpus 2` as the driver runs it (no torchrun, no WORLD_SIZE): the parent spawns two ranks before touching
+    the GPU; PT_BENCH_FAIL_RANK makes one of them exit 1 at start-up, the parent must follow with a non-zero code."""
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(PT_BENCH_FAIL_RANK="1", PT_BENCH_BACKEND="gloo", PT_BENCH_LAUNCH_LIMIT="60")
+    t0 = time.monotonic()
+    r = subprocess.run([os.sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and time.monotonic() - t0 < 90
+    assert "[launch] rank" in r.stderr
