@@ -5,26 +5,24 @@ import torch
 
 from oracle import probtalk_oracle as O
 from probtalk_amd.weights import make_input
-from tests.helpers import golden, ref_state_dict, rel_err
+from oracle.bf16_sim import bf16_operands
+from tests.helpers import check_close, golden, ref_state_dict, rel_err
 
 pytestmark = pytest.mark.gpu
-# bf16 criterion: relative error in the 2-norm, ||gpu - ref|| / ||ref|| < 1e-2 (north_star: "1e-2 in bf16"), plus a
-# guard on the worst element, max|gpu - ref| / max|ref| < 2e-2.  A CPU simulation that only rounds the GEMM operands
-# of the oracle to bf16 (no other change) gives 5.9e-3 / 8.7e-3 on the refiner fixture, i.e. this is the floor of
-# bf16 operands with these random weights, not kernel error; the fp32 path keeps the strict max-based 1e-4.
+# One criterion for both arithmetic modes (tests/helpers.py check_close): ||gpu - ref|| / ||ref|| < tol, tol = 1e-2 here
+# and 1e-4 in the fp32 tests.  The worst element is reported beside it and held to 1.3 x what rounding the oracle's matmul
+# operands to bf16 costs on the CPU (oracle/bf16_sim.py; tools/bf16_error_budget.py prints the split): that floor is
+# 0.9-1.2e-2 of the output range on these fixtures, so 1e-2 on the worst element is not reachable with bf16 operands.
 TOL_BF16 = 1e-2
-TOL_BF16_MAX = 2e-2
 
 
-def l2_err(a, b):
-    a, b = a.double(), b.double()
-    return float((a - b).norm() / b.norm())
-
-
-def check_bf16(a, b, what):
-    e2, emax = l2_err(a, b), rel_err(a, b)
-    print(f"bf16 {what}: l2-rel {e2:.3e}  max-rel {emax:.3e}")
-    assert e2 < TOL_BF16 and emax < TOL_BF16_MAX, what
+def check_bf16(out, ref, what, sim=None):
+    """sim: a callable running the same oracle function (executed under bf16_operands for the floor)."""
+    floor = None
+    if sim is not None:
+        with bf16_operands():
+            floor = sim()
+    return check_close(out, ref, TOL_BF16, "bf16 " + what, operand_floor=floor)
 
 
 def _predictor():
@@ -41,15 +39,17 @@ def test_predictor_logits_bf16():
     label = torch.tensor([1, 3])
     ids = make_input("pred.ids", (2, 11, 4), "int", low=0, high=129)
     logits = pn.decoder.tokens_to_logits(ids.cuda(), label.cuda(), g["condition"].cuda())
-    check_bf16(logits.cpu(), g["logits"], "predictor logits vs reference golden")
-    # config-3 geometry
     sd = ref_state_dict("Predictor")
+    check_bf16(logits.cpu(), g["logits"], "predictor logits vs reference golden",
+               lambda: O.tokens_to_logits(sd, ids, label, g["condition"]))
+    # config-3 geometry
     B, Tq = 3, 37
     cond = make_input("bf.cond", (B, 768, Tq))
     ids = make_input("bf.ids", (B, Tq, 4), "int", low=0, high=129)
     lab = torch.tensor([0, 2, 3])
     out = pn.decoder.tokens_to_logits(ids.cuda(), lab.cuda(), cond.cuda())
-    check_bf16(out.cpu(), O.tokens_to_logits(sd, ids, lab, cond), "predictor logits T'=37")
+    check_bf16(out.cpu(), O.tokens_to_logits(sd, ids, lab, cond), "predictor logits T'=37",
+               lambda: O.tokens_to_logits(sd, ids, lab, cond))
 
 
 def test_predictor_sample_bf16_runs_and_first_pass_matches():
@@ -62,7 +62,10 @@ def test_predictor_sample_bf16_runs_and_first_pass_matches():
                                            noise=(nq.cuda(), ng.cuda()), return_logits=True)
     assert int(codes.min()) >= 0 and int(codes.max()) < 128
     _, ref_logits = O.sample_good(ref_state_dict("Predictor"), label, g["condition"], nq, ng, return_logits=True)
-    check_bf16(logits[0].cpu(), ref_logits[0], "MaskGIT pass-0 logits")   # pass 0 sees the same all-mask input
+    sd = ref_state_dict("Predictor")
+    allmask = torch.full((2, 11, 4), 128, dtype=torch.int32)             # pass 0 sees the same all-mask input in both runs
+    check_bf16(logits[0].cpu(), ref_logits[0], "MaskGIT pass-0 logits",
+               lambda: O.tokens_to_logits(sd, allmask, label, g["condition"]).reshape(2, 44, 128))
     agree = float((codes.cpu() == g["codes"]).float().mean())
     print(f"bf16 MaskGIT codes equal to the fp32 reference run: {agree:.2%} (sampling amplifies rounding; informational)")
 
@@ -78,15 +81,15 @@ def test_refiner_bf16():
     mask = torch.zeros(2, 1, 64)
     mask[:, :, :30] = 1
     out = rt(x.cuda(), aud.cuda(), mask.cuda(), torch.tensor([0, 2]).cuda())
-    check_bf16(out.cpu(), g["out"], "refiner vs reference golden")
     sd = ref_state_dict("HFTransformer")
+    check_bf16(out.cpu(), g["out"], "refiner vs reference golden", lambda: O.rtransformer(sd, x, aud, mask, torch.tensor([0, 2])))
     B, T = 2, 300
     x3, a3 = make_input("ref.x300", (B, 376, T)), make_input("ref.a300", (B, 768, T))
     m3 = torch.zeros(B, 1, T)
     m3[:, :, 100:130] = 1
     lab = torch.tensor([3])
     check_bf16(rt(x3.cuda(), a3.cuda(), m3.cuda(), lab.cuda()).cpu(), O.rtransformer(sd, x3, a3, m3, lab),
-               "refiner T=300")
+               "refiner T=300", lambda: O.rtransformer(sd, x3, a3, m3, lab))
     # switching back restores the fp32 parity path
     rt.set_precision("fp32")
     assert rel_err(rt(x.cuda(), aud.cuda(), mask.cuda(), torch.tensor([0, 2]).cuda()).cpu(), g["out"]) < 1e-4
@@ -108,12 +111,14 @@ def test_vq_decoder_bf16_and_encode_stays_exact():
     x = make_input("vq.x", (2, 376, 88))
     z, qo, _ = vq.encode(x.cuda())
     assert torch.equal(qo.loss.cpu(), g["indices"]), "PQ indices changed in bf16 mode"
-    check_bf16(vq.decode(qo.quantized, None).cpu(), g["recon"], "PQ-VAE decoder vs reference golden")
-    # config-3 geometry: codes (B, 37, 4) -> 296 frames
     sd = ref_state_dict("VQ")
+    check_bf16(vq.decode(qo.quantized, None).cpu(), g["recon"], "PQ-VAE decoder vs reference golden",
+               lambda: O.vqvae_decode(sd, g["quantized"]))
+    # config-3 geometry: codes (B, 37, 4) -> 296 frames
     codes = make_input("bf.codes", (3, 37, 4), "int", low=0, high=128)
     ref = O.vqvae_decode(sd, O.pq_quantize_all(sd, "vq_layer.", codes).permute(0, 2, 1))
-    check_bf16(vq.decode_codes(codes.cuda()).cpu(), ref, "PQ-VAE decode_codes T'=37")
+    check_bf16(vq.decode_codes(codes.cuda()).cpu(), ref, "PQ-VAE decode_codes T'=37",
+               lambda: O.vqvae_decode(sd, O.pq_quantize_all(sd, "vq_layer.", codes).permute(0, 2, 1)))
 
 
 def test_condition_encoders_bf16():
@@ -126,13 +131,14 @@ def test_condition_encoders_bf16():
     aud = make_input("bf.aud", (B, 768, T))
     audio = ae(aud.cuda())
     ref_audio = O.condition_encoder(sd_a, aud)
-    check_bf16(audio.cpu(), ref_audio, "AudEnc T=300")
+    check_bf16(audio.cpu(), ref_audio, "AudEnc T=300", lambda: O.condition_encoder(sd_a, aud))
     pn = _predictor()
     mm = make_input("bf.mm", (B, 376, T))
     mask = torch.zeros(B, 1, T)
     mask[:, :, :30] = 1
     cond = pn.condition(mm.cuda() * mask.cuda(), mask.cuda(), ref_audio.cuda())
-    check_bf16(cond.cpu(), O.predictor_condition(sd_p, mm * mask, mask, ref_audio), "motion-context encoder T=300")
+    check_bf16(cond.cpu(), O.predictor_condition(sd_p, mm * mask, mask, ref_audio), "motion-context encoder T=300",
+               lambda: O.predictor_condition(sd_p, mm * mask, mask, ref_audio))
 
 
 def test_refiner_bf16_long_sequence():
@@ -147,7 +153,8 @@ def test_refiner_bf16_long_sequence():
     m = torch.zeros(B, 1, T)
     m[:, :, 200:260] = 1
     lab = torch.tensor([2])
-    check_bf16(rt(x.cuda(), a.cuda(), m.cuda(), lab.cuda()).cpu(), O.rtransformer(sd, x, a, m, lab), "refiner T=600")
+    check_bf16(rt(x.cuda(), a.cuda(), m.cuda(), lab.cuda()).cpu(), O.rtransformer(sd, x, a, m, lab), "refiner T=600",
+               lambda: O.rtransformer(sd, x, a, m, lab))
 
 
 def test_bf16_large_row_kernels_end_to_end():
@@ -160,7 +167,8 @@ def test_bf16_large_row_kernels_end_to_end():
     ids = make_input("bf.ids16", (B, Tq, 4), "int", low=0, high=129)
     lab = torch.arange(B) % 4
     out = pn.decoder.tokens_to_logits(ids.cuda(), lab.cuda(), cond.cuda())
-    check_bf16(out.cpu(), O.tokens_to_logits(sd, ids, lab, cond), "predictor logits, 2,368 rows")
+    check_bf16(out.cpu(), O.tokens_to_logits(sd, ids, lab, cond), "predictor logits, 2,368 rows",
+               lambda: O.tokens_to_logits(sd, ids, lab, cond))
     from probtalk_amd.nets.transformer_modules import RTransformer
     rt = RTransformer(376, 768, 512, 6, use_label=True, motion_context=True).eval()
     rt.load_state_dict(ref_state_dict("HFTransformer"))
@@ -171,4 +179,40 @@ def test_bf16_large_row_kernels_end_to_end():
     m = torch.zeros(B, 1, T)
     m[:, :, 40:90] = 1
     lab = torch.arange(B) % 4
-    check_bf16(rt(x.cuda(), a.cuda(), m.cuda(), lab.cuda()).cpu(), O.rtransformer(sdr, x, a, m, lab), "refiner, 2,400 rows")
+    check_bf16(rt(x.cuda(), a.cuda(), m.cuda(), lab.cuda()).cpu(), O.rtransformer(sdr, x, a, m, lab), "refiner, 2,400 rows",
+               lambda: O.rtransformer(sdr, x, a, m, lab))
+
+
+def test_bf16_pipeline_tail_from_oracle_codes():
+    """The tail of the pipeline in bf16 mode on the ORACLE's codes (sampling amplifies rounding, so the sampled codes of a
+    bf16 run are not comparable; everything after them is): codes -> PQ gather + bf16 conv decoder -> resize / blend ->
+    bf16 refiner -> blend, against the fp32 oracle on the same codes."""
+    import torch.nn.functional as F
+    from probtalk_amd.synthetic import build_pipeline
+    pred, ref = build_pipeline(seed=0)
+    pred._eval()
+    for mod in (pred.VQ, ref.RTransformer):
+        mod.set_precision("bf16")
+    sd_vq, sd_r = pred.VQ.state_dict(), ref.RTransformer.state_dict()
+    B, T, Tq = 3, 300, 37
+    aud = make_input("tail.aud", (B, 768, T))
+    gt = make_input("tail.gt", (B, 376, T))
+    mask = torch.zeros(B, 1, T)
+    mask[:, :, :30] = 1
+    ids = torch.tensor([0, 1, 3])
+    codes = make_input("tail.codes", (B, Tq, 4), "int", low=0, high=128)
+
+    def oracle_tail():
+        e = O.pq_quantize_all(sd_vq, "vq_layer.", codes).transpose(1, 2)
+        body = F.interpolate(O.vqvae_decode(sd_vq, e), size=T, mode="linear")
+        body = gt * mask * mask + body * (1 - mask)
+        return O.refiner_infer(sd_r, aud, gt, mask, ids, body)
+
+    from probtalk_amd import _lib
+    L = _lib.lib()
+    dec = pred.VQ.decode_codes(codes.cuda())
+    body = torch.empty(B, 376, T, device="cuda")
+    gtd, md = gt.cuda().contiguous(), mask.cuda().contiguous()
+    _lib.check(L.pt_interp_blend(_lib.ptr(dec), B, 376, dec.shape[2], T, _lib.ptr(gtd), _lib.ptr(md), 1, _lib.ptr(body), _lib.stream()))
+    out, _ = ref.infer_on_batch(aud=aud.cuda(), B=B, id=ids.cuda(), gt_poses=gtd, mask=md, pred_poses=body)
+    check_bf16(out.cpu(), oracle_tail(), "pipeline tail (oracle codes -> decode -> refine)", oracle_tail)
