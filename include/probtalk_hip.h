@@ -155,6 +155,19 @@ int pt_gemm_bf16_lnmod(const void* A, int lda, const void* W, const float* bias,
  * residual path; 1 KB read + 1 KB written per row instead of 2 KB + 3 KB). */
 int pt_gemm_bf16_addln(const void* A, int lda, const void* W, const float* bias, int M, int K, int Npad,
                        const float* gamma, const float* beta, float* x, void* x_bf16, void* stream);
+/* The whole tail of a decoder sub-layer in one launch, rows kept in registers between the products (DeepSupervisionLayer,
+ * PTransformer.py:329-331 around StylizationBlock_V3 'sb', :134-140):
+ *   t = A.W1^T + b1 (A [M, lda] bf16, W1 [512][K1] bf16, K1 = 512 attention out-proj / 2048 FFN-2)
+ *   h = SiLU(LN(t) folded with the per-class style table, as pt_gemm_bf16_lnmod)
+ *   x_bf16[M,512] = LN(x_bf16 + h.W2^T + b2; gamma, beta) in place (bf16 residual stream, as pt_gemm_bf16_addln with x == NULL)
+ * W2p is [512][512] bf16 with the K axis permuted by pt_permute_k32 (the accumulator layout of one product is the operand
+ * layout of the next up to that permutation).  n_classes <= 4.  The model path uses it where whole rounds of its
+ * persistent grid beat the two launches above. */
+int pt_gemm_bf16_sublayer(const void* A, int lda, int K1, const void* W1, const float* b1, const float* style_folded,
+                          const int64_t* label, int n_label, int rows_per_clip, int n_classes, const void* W2p, const float* b2,
+                          const float* gamma, const float* beta, void* x_bf16, int M, void* stream);
+/* out[n][32 kb + 8 q + j] = W[n][32 kb + (j < 4 ? 4 q + j : 16 + 4 q + (j - 4))] for a [N][K] bf16 matrix, K % 32 == 0. */
+int pt_permute_k32(const void* W, void* out, int N, int K, void* stream);
 /* softmax(Q K^T / 8) V per (clip, head), head dim 64 (nn.MultiheadAttention core, PTransformer.py:340-353):
  * Q rows b*Nq+i at Q + row*ldq + head*64; K/V rows b*Nk+j likewise; O like Q. */
 int pt_attention_cl(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,
@@ -260,9 +273,18 @@ int pt_train_masked_l1_losses(const float* pred, int ldp, const float* gt, int l
 int pt_train_sqdiff(const float* a, const float* b, size_t n, float* out, void* stream);
 int pt_train_commit_bwd(const float* dq, const float* z, const float* q, const float* g, float coef, size_t n, float* dz,
                         void* stream);
-/* debug aid: device buffer of 256*64 uint64 that the following pt_gemm_bf16* calls fill with per-workgroup phase
- * timestamps (tools/gemm_stamps.py); NULL switches it off */
-int pt_debug_set_stamps(void* buf);
+/* The library's only run-time switches; it reads no environment variables.  Set them before the calls they affect, from
+ * one thread (they are plain process-wide ints).  No counterpart in the reference: they select between kernels that
+ * compute the same thing (A/B measurements and tests), except resid_bf16, which moves the bf16 mode's rounding points.
+ *   "resid_bf16"         1 (default) bf16 mode keeps the residual stream in bf16; 0 = fp32 stream with a bf16 shadow
+ *   "fused_tail"         -1 (default) one-launch sub-layer tail (pt_gemm_bf16_sublayer) where whole rounds of its grid
+ *                        pay; 0 never; 1 wherever it applies
+ *   "small_rows"         rows up to which wide Linears (N != 512) take the 4-wave kernel (default 2048)
+ *   "row_tile"           0 (default) the N = 512 row kernel picks its tile height; 2 | 4 | 8 | 10 forces 16 x that many rows
+ *   "attn_train_rowwise" 1 = training attention on the row-wise kernels whatever the shape (default 0)
+ * Unknown names and out-of-range values are errors (non-zero return, pt_last_error). */
+int pt_set_option(const char* name, int value);
+int pt_get_option(const char* name, int* value);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,8 @@ def _proto(lib):
     lib.pt_gemm_bf16.argtypes = [vp, i, vp, vp, i, i, i, i, vp, i, vp, i, i, vp]
     lib.pt_gemm_bf16_lnmod.argtypes = [vp, i, vp, vp, i, i, i, vp, vp, i, i, i, vp, vp]
     lib.pt_gemm_bf16_addln.argtypes = [vp, i, vp, vp, i, i, i, vp, vp, vp, vp, vp]
+    lib.pt_gemm_bf16_sublayer.argtypes = [vp, i, i, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, i, vp]
+    lib.pt_permute_k32.argtypes = [vp, vp, i, i, vp]
     f, u64, sz = C.c_float, C.c_uint64, C.c_size_t
     lib.pt_embed_pe.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
     lib.pt_train_wgrad.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, vp]
@@ -86,7 +88,8 @@ def _proto(lib):
     lib.pt_train_masked_l1_losses.argtypes = [vp, i, vp, i, vp, f, i, i, i, vp, vp, i, vp, vp, i, vp]
     lib.pt_train_sqdiff.argtypes = [vp, vp, sz, vp, vp]
     lib.pt_train_commit_bwd.argtypes = [vp, vp, vp, vp, f, sz, vp, vp]
-    lib.pt_debug_set_stamps.argtypes = [vp]
+    lib.pt_set_option.argtypes = [C.c_char_p, i]
+    lib.pt_get_option.argtypes = [C.c_char_p, vp]
     lib.pt_attention_cl.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, vp]
     lib.pt_attention_bf16.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, vp]
     for name in EXPORTS:
@@ -103,13 +106,13 @@ EXPORTS = [
     "pt_predictor_workspace_bytes", "pt_predictor_condition", "pt_predictor_logits", "pt_predictor_sample", "pt_predictor_sample_seeded", "pt_predictor_sample_seed_dev", "pt_maskgit_noise", "pt_maskgit_noise_from_bits",
     "pt_refiner_workspace_bytes", "pt_refiner_forward", "pt_interp_blend", "pt_conv1d_cl", "pt_ncl_to_cl",
     "pt_cl_to_ncl", "pt_pq_search_cl", "pt_pq_gather_cl", "pt_attention_cl", "pt_attention_bf16", "pt_gemm_bf16", "pt_gemm_bf16_lnmod",
-    "pt_gemm_bf16_addln", "pt_prof_enable",
+    "pt_gemm_bf16_addln", "pt_gemm_bf16_sublayer", "pt_permute_k32", "pt_prof_enable",
     "pt_prof_read", "pt_embed_pe", "pt_train_wgrad", "pt_train_colsum", "pt_train_ln_fwd", "pt_train_ln_bwd",
     "pt_train_modsilu_fwd", "pt_train_modsilu_bwd", "pt_train_attention_fwd", "pt_train_attention_bwd",
     "pt_train_cross_entropy", "pt_train_bn_fwd", "pt_train_bn_bwd", "pt_train_act_bwd", "pt_train_gate_fwd",
     "pt_train_gate_bwd", "pt_train_embed_bwd", "pt_train_dropout", "pt_train_sumsq", "pt_train_clip_coef",
     "pt_train_adamw", "pt_train_add", "pt_train_pq_ema", "pt_train_vq_ema", "pt_train_vq_losses", "pt_train_masked_l1_losses", "pt_train_sqdiff", "pt_train_commit_bwd",
-    "pt_debug_set_stamps",
+    "pt_set_option", "pt_get_option",
 ]
 
 

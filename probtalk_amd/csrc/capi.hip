@@ -71,12 +71,42 @@ int scratch_for_current_device(void** out) {
   *out = g_scratch_ptr[dev];
   return 0;
 }
+
+// ---- run-time options (pt_common.h: Option).  Plain ints: set them before the calls they affect, from one thread.
+int g_opt[pt::OPT_COUNT] = {1, -1, 2048, 0, 0};
+const char* const g_opt_name[pt::OPT_COUNT] = {"resid_bf16", "fused_tail", "small_rows", "row_tile", "attn_train_rowwise"};
+int find_option(const char* name) {
+  if (name)
+    for (int i = 0; i < pt::OPT_COUNT; ++i)
+      if (strcmp(name, g_opt_name[i]) == 0) return i;
+  return -1;
+}
 }  // namespace
+
+namespace pt {
+int option(Option o) { return g_opt[o]; }
+}  // namespace pt
 
 extern "C" {
 
 const char* pt_last_error(void) { return last_error(); }
 int pt_version(void) { return 100; }
+
+int pt_set_option(const char* name, int value) {
+  const int i = find_option(name);
+  PT_CHECK(i >= 0, "pt_set_option: unknown option '%s' (resid_bf16, fused_tail, small_rows, row_tile, attn_train_rowwise)", name ? name : "(null)");
+  PT_CHECK(i != OPT_ROW_TILE || value == 0 || value == 2 || value == 4 || value == 8 || value == 10, "pt_set_option: row_tile = 0, 2, 4, 8 or 10");
+  PT_CHECK(i != OPT_FUSED_TAIL || (value >= -1 && value <= 1), "pt_set_option: fused_tail = -1 (auto), 0 or 1");
+  PT_CHECK(i != OPT_SMALL_ROWS || value >= 0, "pt_set_option: small_rows >= 0");
+  g_opt[i] = value;
+  return 0;
+}
+int pt_get_option(const char* name, int* value) {
+  const int i = find_option(name);
+  PT_CHECK(i >= 0 && value, "pt_get_option: unknown option '%s'", name ? name : "(null)");
+  *value = g_opt[i];
+  return 0;
+}
 
 pt_model* pt_model_create(const char* kind, const int* cfg, int ncfg) {
   static const char* kinds[] = {"vqvae_sc", "vqvae_legacy", "cond_encoder", "predictor", "refiner"};
@@ -302,9 +332,6 @@ int pt_prof_read(double* ms8, double* flops8, int* launches8) {
   PT_CHECK(ms8 && flops8 && launches8, "pt_prof_read: null argument");
   return prof_read(ms8, flops8, launches8);
 }
-static unsigned long long* g_stamps = nullptr;
-/* debug aid: device buffer of 256*64 uint64 that the next pt_gemm_bf16* calls fill with phase timestamps */
-int pt_debug_set_stamps(void* buf) { g_stamps = (unsigned long long*)buf; return 0; }
 int pt_gemm_bf16(const void* A, int lda, const void* W, const float* bias, int M, int N, int K, int Npad, float* C,
                  int ldc, void* Cb, int ldcb, int relu, void* stream) {
   PT_CHECK(A && W && (C || Cb), "pt_gemm_bf16: null argument");
@@ -314,7 +341,6 @@ int pt_gemm_bf16(const void* A, int lda, const void* W, const float* bias, int M
     b.A = (const unsigned short*)A; b.lda = lda; b.W = (const unsigned short*)W; b.bias = bias;
     b.M = M; b.N = N; b.K = K; b.Npad = Npad; b.epi = EPI_STD;
     b.C = C; b.ldc = ldc; b.Cb = (unsigned short*)Cb; b.ldcb = ldcb; b.relu = relu;
-    b.stamps = g_stamps;
     return launch_gemm_big(b, (hipStream_t)stream);
   }
   GemmArgsB a;
@@ -334,7 +360,7 @@ int pt_gemm_bf16_lnmod(const void* A, int lda, const void* W, const float* bias,
   memset(&b, 0, sizeof(b));
   b.A = (const unsigned short*)A; b.lda = lda; b.W = (const unsigned short*)W; b.bias = bias;
   b.M = M; b.N = 512; b.K = K; b.Npad = Npad; b.epi = EPI_LNMOD;
-  b.Cb = (unsigned short*)out_bf16; b.ldcb = 512; b.style = style_folded; b.stamps = g_stamps;
+  b.Cb = (unsigned short*)out_bf16; b.ldcb = 512; b.style = style_folded;
   b.label = label; b.n_label = n_label; b.rows_per_clip = rows_per_clip; b.n_classes = n_classes;
   return launch_gemm_big(b, (hipStream_t)stream);
 }
@@ -345,8 +371,22 @@ int pt_gemm_bf16_addln(const void* A, int lda, const void* W, const float* bias,
   memset(&b, 0, sizeof(b));
   b.A = (const unsigned short*)A; b.lda = lda; b.W = (const unsigned short*)W; b.bias = bias;
   b.M = M; b.N = 512; b.K = K; b.Npad = Npad; b.epi = EPI_ADDLN;
-  b.Cb = (unsigned short*)x_bf16; b.ldcb = 512; b.gamma = gamma; b.beta = beta; b.X = x; b.stamps = g_stamps;
+  b.Cb = (unsigned short*)x_bf16; b.ldcb = 512; b.gamma = gamma; b.beta = beta; b.X = x;
   return launch_gemm_big(b, (hipStream_t)stream);
+}
+int pt_permute_k32(const void* W, void* out, int N, int K, void* stream) {
+  return launch_permute_k32((const unsigned short*)W, (unsigned short*)out, N, K, (hipStream_t)stream);
+}
+int pt_gemm_bf16_sublayer(const void* A, int lda, int K1, const void* W1, const float* b1, const float* style_folded,
+                          const int64_t* label, int n_label, int rows_per_clip, int n_classes, const void* W2p, const float* b2,
+                          const float* gamma, const float* beta, void* x_bf16, int M, void* stream) {
+  SubArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = (const unsigned short*)A; a.lda = lda; a.K1 = K1; a.W1 = (const unsigned short*)W1; a.b1 = b1;
+  a.fold = style_folded; a.label = label; a.n_label = n_label; a.rows_per_clip = rows_per_clip; a.n_classes = n_classes;
+  a.W2p = (const unsigned short*)W2p; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.X = (unsigned short*)x_bf16;
+  a.M = M;
+  return launch_sublayer(a, (hipStream_t)stream);
 }
 int pt_attention_cl(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, int B,
                     int Nq, int Nk, int H, void* stream) {

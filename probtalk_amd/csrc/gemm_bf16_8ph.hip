@@ -57,13 +57,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  if (p.stagger > 0) {
-    // spread the workgroups' start times: left alone, all 256 CUs run their main loops together and then store their
-    // tiles together, so the HBM write burst and the MFMA work serialise instead of overlapping
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long d = (unsigned long long)(((blockIdx.x >> 3) * 5 + (blockIdx.x & 7) * 2) & 15) * p.stagger >> 4;
-    while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(8);
-  }
   const int r = lane & 15, q4 = lane >> 4;
   const int nt = p.K >> 6;
 
@@ -127,12 +120,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
   bf16x8 af[4][2], bfr[2][2][2];
   int cbuf = 0;
 
-  int stamp_i = 0;
-  auto stamp = [&]() {
-    if (p.stamps && tid == 0 && stamp_i < 64 && blockIdx.x < 256) p.stamps[blockIdx.x * 64 + stamp_i++] = __builtin_amdgcn_s_memrealtime();
-  };
   for (int tile = tile0; tile < ntiles; tile += G) {
-    stamp();                                             // [0] tile start
     {
       // accumulators start at the bias (its loads overlap the first K-tile instead of standing in the epilogue)
       int iq = q4;
@@ -188,7 +176,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
       };
       // P1
       readB(0); readA(0); issue(3); wait();
-      if (t == 1) stamp();                               // [1] first counted wait of the tile passed
       mma(0, 0);
       // P2
       readB(1); issue(1); wait(); mma(0, 1);
@@ -198,13 +185,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
       issue(2); wait(); mma(1, 0);
     }
 
-    stamp();                                             // [2] main loop done
     // ---- epilogue.  acc[i][j][e]: row m = m0 + wr*128 + i*16 + r, column n = n0 + wc*64 + j*16 + 4*q4 + e
     // (lane coordinates laundered so that the address arithmetic is not hoisted into the main loop's registers)
     int er = r, eq = q4;
     asm volatile("" : "+v"(er), "+v"(eq));
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int mw = (p.zero_to == -2 ? 0 : tm * 256) + wr * 128, nw = tn * 256 + wc * 64;   // DEBUG zero_to -2: every tile stores to m-tile 0
+    const int mw = tm * 256 + wr * 128, nw = tn * 256 + wc * 64;
     const int ncols = p.N > p.zero_to ? p.N : p.zero_to;
     if (p.pe || p.Res || p.relu || nw + 64 > p.N) {
 #pragma unroll
@@ -233,12 +219,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
     }
     // everything staged so far has landed before the stores join the vmcnt queue (see the header)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    stamp();                                             // [3] epilogue arithmetic done, staged K-tiles landed
     // fp32 rows leave straight from the accumulators (16 rows x 64 B per instruction); bf16: accumulators j and j+1
     // exchange 16-lane rows (v_permlane16_swap), then a lane holds 8 consecutive bf16 columns
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      if (p.zero_to == -1) break;   // DEBUG: no stores
       const int m = mw + i * 16 + er;
       const bool live = m < p.M;
       if (p.C) {
@@ -262,9 +246,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
       }
       asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3])::"memory");
     }
-    stamp();                                             // [4] stores issued
   }
-  if (wr == 0) __builtin_amdgcn_s_barrier();                    // balances the stagger barrier of waves 4-7
+  if (wr == 0) __builtin_amdgcn_s_barrier();                    // balances the extra barrier waves 4-7 took in the prologue
 }
 
 static int g8_num_cus = 0;
@@ -283,13 +266,9 @@ int launch_gemm8(const GemmBigArgs& a, int cfg, hipStream_t s) {
   }
   const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256, ntiles = tiles_m * tiles_n;
   const int grid = ntiles < g8_num_cus ? ntiles : g8_num_cus;
-  static int stagger_us = -1;
-  if (stagger_us < 0) { const char* e = getenv("PT_GEMM_STAGGER"); stagger_us = e ? atoi(e) : 0; }
-  GemmBigArgs b = a;
-  b.stagger = ntiles > grid ? stagger_us * 100 : 0;
   void* tok = nullptr;
   if (prof_is_on()) prof_record_begin(s, a.flops > 0 ? a.flops : 2.0 * a.M * a.N * a.K, cfg, &tok);
-  PT_LAUNCH(gemm8_kernel, dim3(grid), dim3(512), G8_SMEM, s, b, tiles_n, ntiles);
+  PT_LAUNCH(gemm8_kernel, dim3(grid), dim3(512), G8_SMEM, s, a, tiles_n, ntiles);
   if (tok) prof_record_end(s, tok);
   return 0;
 }

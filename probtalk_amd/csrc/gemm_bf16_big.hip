@@ -8,13 +8,13 @@
 // MFMA operands are swapped (W fragment first), so a lane owns ONE output row m and 4 consecutive
 // columns per register quad: 16-byte fp32 / 8-byte bf16 stores, and row reductions are in-lane.
 //
-// Two tile shapes:
-//   256 x 256  (wave tile 128 x 64): in-proj, FFN-1, heads       -> EPI_STD epilogue
-//   128 x 512  (wave tile 64 x 128): every N = 512 Linear; a workgroup owns whole rows, so the
-//       LayerNorm that follows the Linear in the decoder layer is fused into the epilogue:
-//       EPI_LNMOD  out = SiLU(LN(acc + bias) * (1 + scale[label]) + shift[label])  -> bf16   (PTransformer.py:134-139;
-//                  the LayerNorm affine is folded into per-class tables G = gamma(1+scale), B = beta(1+scale)+shift)
-//       EPI_ADDLN  x   = LN(x + acc + bias)                                       -> fp32 x and bf16 copy (:329-331)
+// This is the general kernel: it takes what the phase-pipelined kernels (gemm_bf16_8ph.hip, gemm_bf16_row.hip) do not:
+//   256 x 256  (wave tile 128 x 64), EPI_STD: K = 64 (the 8-phase kernel needs two K-tiles in flight)
+//   128 x 512  (wave tile 64 x 128), EPI_STD: N = 512 Linears with the fp64 positional table, a residual or zero-padded
+//              columns in the epilogue (input / audio / condition embeddings)
+//   128 x 512, EPI_LNMOD: out = SiLU(LN(acc + bias) * (1 + scale[label]) + shift[label]) -> bf16 (PTransformer.py:134-139)
+//              with more than 4 style classes (the row kernel keeps 4 classes of tables in LDS); a workgroup owns whole
+//              rows, the LayerNorm affine is folded into per-class tables G = gamma(1+scale), B = beta(1+scale)+shift
 #include <cstdlib>
 
 #include "pt_common.h"
@@ -116,12 +116,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_big_kernel(const GemmBigArg
     set_src(tile);
     stage(0, 0, 0, NLD);
   }
-  int stamp_i = 0;
-  auto stamp = [&]() {
-    if (p.stamps && tid == 0 && stamp_i < 64 && blockIdx.x < 256) p.stamps[blockIdx.x * 64 + stamp_i++] = __builtin_amdgcn_s_memrealtime();
-  };
   for (; tile < ntiles; tile += G) {
-    stamp();                                            // [0] tile start
     const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     // accumulators start at the bias (its loads overlap the wait for the tile's first K-tile, which is idle time)
@@ -142,7 +137,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_big_kernel(const GemmBigArg
     for (int t = 0; t < nt; ++t, ++gt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                     // K-tile landed for every wave; everyone is done with the other buffer
-      if (t == 0) stamp();                 // [1] first K-tile landed
       const bool more = t + 1 < nt;
       const unsigned char* Ab = smem + (gt & 1) * STAGE + (wm * TM) * RB;
       const unsigned char* Bb = smem + (gt & 1) * STAGE + (BM + wn * TN) * RB;
@@ -166,7 +160,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_big_kernel(const GemmBigArg
       }
     }
     __syncthreads();                                   // every wave is done with the stage buffers of this tile
-    stamp();                                           // [2] main loop done
     unsigned char* ebuf = smem + ((gt - 1) & 1) * STAGE;          // free now: slabs and reduction scratch
     unsigned char* slab = ebuf + wave * SLAB;
     const bool has_next = tile + G < ntiles;
@@ -209,26 +202,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_big_kernel(const GemmBigArg
       float mean[MI], rstd[MI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        const int m = mrow0 + mi * 32;
-        const bool live = m < p.M;
         float sum = 0.f;
-        if (EPI == EPI_ADDLN) {
-          // the row's 16 residual quads are requested together (memory-level parallelism), one row block at a time
-          f32x4 xv[NI][4];
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              xv[ni][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-              if (live) xv[ni][g] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * 512 + ncol0 + ni * 32 + 8 * g);
-            }
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc[mi][ni][4 * g + e] += xv[ni][g][e];
-        }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
@@ -267,20 +241,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_big_kernel(const GemmBigArg
         for (int w = 0; w < WN; ++w) tot += rq[w * BM + lr];
         rstd[mi] = __builtin_amdgcn_rsqf(tot * (1.f / 512.f) + 1e-5f);
       }
-      // normalise in place.  LNMOD: the per-class tables hold gamma*(1+scale) and beta*(1+scale)+shift, so
+      // normalise in place: the per-class tables hold gamma*(1+scale) and beta*(1+scale)+shift, so
       // SiLU(LN(v)*(1+scale)+shift) = SiLU((v-mean)*rstd*G[c] + B[c])
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int m = mrow0 + mi * 32;
-        const float* gp = p.gamma;
-        const float* bp = p.beta;
-        if (EPI == EPI_LNMOD) {
-          const int mc = m < p.M ? m : p.M - 1;
-          long long lb = p.label[p.n_label == 1 ? 0 : mc / p.rows_per_clip];
-          lb = lb < 0 ? 0 : (lb >= p.n_classes ? p.n_classes - 1 : lb);
-          gp = p.style + (size_t)lb * 1024;
-          bp = gp + 512;
-        }
+        const int mc = m < p.M ? m : p.M - 1;
+        long long lb = p.label[p.n_label == 1 ? 0 : mc / p.rows_per_clip];
+        lb = lb < 0 ? 0 : (lb >= p.n_classes ? p.n_classes - 1 : lb);
+        const float* gp = p.style + (size_t)lb * 1024;
+        const float* bp = gp + 512;
         // table rows of the next 32-column block are requested before this block's arithmetic (software pipeline)
         f32x4 ga[2][4], be[2][4];
 #pragma unroll
@@ -302,7 +272,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_big_kernel(const GemmBigArg
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float y = (acc[mi][ni][4 * g + e] - mean[mi]) * rstd[mi] * ga[ni & 1][g][e] + be[ni & 1][g][e];
-              if (EPI == EPI_LNMOD) y = y * __builtin_amdgcn_rcpf(1.f + __expf(-y));
+              y = y * __builtin_amdgcn_rcpf(1.f + __expf(-y));
               acc[mi][ni][4 * g + e] = y;
             }
           }
@@ -318,7 +288,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_big_kernel(const GemmBigArg
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
 
-    stamp();                                           // [3] epilogue arithmetic done
     // ---- the next tile's first K-tile starts flowing into the other buffer while this tile is stored
     if (has_next) {
       set_src(tile + G);
@@ -327,9 +296,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_big_kernel(const GemmBigArg
 
     // ---- epilogue part 2: accumulator layout (a lane owns 4 consecutive columns of ONE row: 32 rows per store
     // instruction) -> wave-private LDS slab -> row-contiguous 16-byte stores.  No global loads from here on.
-    const bool want_f32 = (EPI == EPI_ADDLN) || (EPI == EPI_STD && p.C != nullptr);
-    float* outf = EPI == EPI_ADDLN ? p.X : p.C;
-    const int ldf = EPI == EPI_ADDLN ? 512 : p.ldc;
+    const bool want_f32 = EPI == EPI_STD && p.C != nullptr;
+    float* outf = p.C;
+    const int ldf = p.ldc;
     const int ncols = EPI == EPI_STD ? (p.N > p.zero_to ? p.N : p.zero_to) : 512;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -385,7 +354,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_big_kernel(const GemmBigArg
         }
       }
     }
-    stamp();                                           // [4] stores issued
   }
 }
 
@@ -416,30 +384,8 @@ static int launch_big(const GemmBigArgs& a, int cfg, hipStream_t s) {
   return 0;
 }
 
-// row-complete (N = 512) configuration: 0 = 128x512 tiles, 8 waves, BK 64, one workgroup per CU (default);
-// 1 = 64x512 tiles, 4 waves, BK 32, two workgroups per CU: measured 1.8x SLOWER (each 64-row tile still streams the
-// whole 512 x K weight panel through the CU's L2 port, ~13 us per panel either way).  PT_GEMM_ROWCFG=1 selects it.
-static int row_cfg() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PT_GEMM_ROWCFG"); v = e ? atoi(e) : 0; }
-  return v;
-}
-
 int launch_gemm8(const GemmBigArgs& a, int cfg, hipStream_t s);
 int launch_gemm_row(const GemmBigArgs& a, hipStream_t s);
-// PT_GEMM_ROW: 1 (default) = N = 512 Linears go to the phase-pipelined row kernel (gemm_bf16_row.hip), 0 = two-stage kernel here
-static int gemm_row_mode() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PT_GEMM_ROW"); v = e ? atoi(e) : 1; }
-  return v;
-}
-// PT_GEMM8: 0 = keep the two-stage kernel for the 256 x 256 tile, 1 (default) = phase-pipelined kernel (gemm_bf16_8ph.hip)
-// for EPI_STD with N != 512, 2 = also for N == 512.
-static int gemm8_mode() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PT_GEMM8"); v = e ? atoi(e) : 1; }
-  return v;
-}
 
 int launch_gemm_big(const GemmBigArgs& a, hipStream_t s) {
   PT_CHECK(a.M > 0 && a.N > 0, "gemm_big: empty problem M=%d N=%d", a.M, a.N);
@@ -449,7 +395,7 @@ int launch_gemm_big(const GemmBigArgs& a, hipStream_t s) {
   PT_CHECK(a.N % 8 == 0, "gemm_big: N=%d must be a multiple of 8", a.N);
   PT_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm_big: A and W must be 16-byte aligned");
   PT_CHECK((double)a.M * a.lda * 2 < 4.0e9 && (double)a.Npad * a.K * 2 < 4.0e9, "gemm_big: operand larger than 4 GB");
-  const bool row_ok = gemm_row_mode() >= 1 && a.N == 512 && a.Npad == 512 && a.K >= 64;
+  const bool row_ok = a.N == 512 && a.Npad == 512;
   if (a.epi == EPI_STD) {
     PT_CHECK(a.C || a.Cb, "gemm_big: no output");
     PT_CHECK((!a.C || (a.ldc >= a.N && a.ldc % 4 == 0 && ((uintptr_t)a.C & 15) == 0)) &&
@@ -460,15 +406,8 @@ int launch_gemm_big(const GemmBigArgs& a, hipStream_t s) {
     PT_CHECK(!a.Res || (a.ldr % 4 == 0 && ((uintptr_t)a.Res & 15) == 0), "gemm_big: residual must be 16-byte aligned rows");
     PT_CHECK(!a.pe || (a.pe_period > 0 && ((uintptr_t)a.pe & 31) == 0), "gemm_big: pe table needs a period and 32-byte alignment");
     if (row_ok && !a.pe && !a.Res && a.zero_to == 0) return launch_gemm_row(a, s);
-    if (a.K >= 128 && ((a.N != 512 && gemm8_mode() >= 1) || gemm8_mode() >= 2)) {
-      static int dbg = -9;
-      if (dbg == -9) { const char* e = getenv("PT_GEMM8_DBG"); dbg = e ? atoi(e) : 0; }
-      if (dbg == 0) return launch_gemm8(a, 6, s);
-      GemmBigArgs b = a;
-      b.zero_to = -dbg;
-      return launch_gemm8(b, 6, s);
-    }
-    if (a.N == 512) return row_cfg() == 0 ? launch_big<128, 512, 2, 4, 64, EPI_STD, 1>(a, 7, s) : launch_big<64, 512, 1, 4, 32, EPI_STD, 2>(a, 7, s);
+    if (a.K >= 128 && a.N != 512) return launch_gemm8(a, 6, s);
+    if (a.N == 512) return launch_big<128, 512, 2, 4, 64, EPI_STD, 1>(a, 7, s);
     return launch_big<256, 256, 2, 4, 64, EPI_STD, 1>(a, 6, s);
   }
   PT_CHECK(a.N == 512, "gemm_big: fused LayerNorm epilogues need N = 512 (got %d)", a.N);
@@ -480,13 +419,12 @@ int launch_gemm_big(const GemmBigArgs& a, hipStream_t s) {
     PT_CHECK(a.n_label == 1 || (long long)a.n_label * a.rows_per_clip >= a.M, "gemm_big: %d labels x %d rows < M=%d",
              a.n_label, a.rows_per_clip, a.M);
     if (row_ok && a.n_classes <= 4) return launch_gemm_row(a, s);      // the row kernel keeps 4 classes of style tables in LDS
-    return row_cfg() == 0 ? launch_big<128, 512, 2, 4, 64, EPI_LNMOD, 1>(a, 7, s) : launch_big<64, 512, 1, 4, 32, EPI_LNMOD, 2>(a, 7, s);
+    return launch_big<128, 512, 2, 4, 64, EPI_LNMOD, 1>(a, 7, s);
   }
   PT_CHECK(a.epi == EPI_ADDLN && a.gamma && a.beta && ((uintptr_t)a.X & 15) == 0,
            "gemm_big: ADDLN epilogue needs gamma, beta and a 16-byte aligned residual stream");
-  if (row_ok) return launch_gemm_row(a, s);          // X == nullptr: bf16 residual stream, Cb updated in place
-  PT_CHECK(a.X, "gemm_big: the bf16 residual stream (X == nullptr) needs the row kernel (N = 512, K >= 64, PT_GEMM_ROW on)");
-  return row_cfg() == 0 ? launch_big<128, 512, 2, 4, 64, EPI_ADDLN, 1>(a, 7, s) : launch_big<64, 512, 1, 4, 32, EPI_ADDLN, 2>(a, 7, s);
+  PT_CHECK(row_ok, "gemm_big: the residual + LayerNorm epilogue needs N = Npad = 512");
+  return launch_gemm_row(a, s);          // X == nullptr: bf16 residual stream, Cb updated in place
 }
 
 }  // namespace pt

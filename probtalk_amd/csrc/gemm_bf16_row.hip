@@ -61,15 +61,9 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
   const int tile0 = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;                         // stagger half: 0 = waves 0-3, 1 = waves 4-7
+  const int grp = wave >> 2;                         // half: 0 = waves 0-3, 1 = waves 4-7 (one barrier behind)
   const int r = lane & 15, q4 = lane >> 4;
   const int nt = p.K >> 5;
-  if (p.stagger > 0 && (blockIdx.x & 8)) {
-    // half of the workgroups start late: left alone, all CUs run their main loops together (HBM idle) and then
-    // their HBM-bound epilogues together (matrix cores idle)
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(8);
-  }
   const bool extra = MT > 8 && wave + 8 < MT;        // this wave issues a second A instruction per K-tile
 
   // ---- DMA streams.  One wave-instruction = 16 image rows x 64 B; lane -> row (lane >> 2), LDS chunk (lane & 3).
@@ -158,17 +152,12 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
   int cbuf = 0;
   float* red = reinterpret_cast<float*>(smem + GR_RED);
 
-  int stamp_i = 0;
-  auto stamp = [&]() {
-    if (p.stamps && tid == 0 && stamp_i < 64 && blockIdx.x < 256) p.stamps[blockIdx.x * 64 + stamp_i++] = __builtin_amdgcn_s_memrealtime();
-  };
 
   // keeps one 16-row block's values in place: without it the compiler hoists every epilogue load above the arithmetic
   // of all blocks and spills hundreds of registers
 #define PT_PIN_BLOCK(i)                                                   \
   asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3])::"memory")
   for (int tile = tile0; tile < ntiles; tile += G) {
-    stamp();                                                     // [0]
     // accumulators start at the bias.  (Starting them at bias + residual row for EPI_ADDLN was measured: the 320 KB of x per
     // tile then stand in front of the first MFMAs, 142 us against 130 us per launch at 75,776 rows.)
     {
@@ -216,7 +205,6 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
         else if (extra) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // B-lo 2 + (A 2 + B-hi 2) + B-lo 2
         else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                  // B-lo 2 + (A 1 + B-hi 2) + B-lo 2
       }
-      if (t == 2) stamp();                                       // [1]
       mma(0);
       // P2
 #pragma unroll
@@ -229,7 +217,6 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
       }
       mma(1);
     }
-    stamp();                                                     // [2] main loop done
 
     // ---- epilogue.  acc[i][j][e]: row m = tile*BM + i*16 + er, column n = wave*64 + j*16 + 4*eq + e
     // (lane coordinates are laundered through an empty asm so that the epilogue's address arithmetic is not hoisted out
@@ -376,7 +363,6 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
       // every K-tile staged so far has landed before the stores join the in-order vmcnt queue
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      stamp();                                                   // [3] statistics done
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         float tot = 0.f, totq = 0.f;
@@ -415,19 +401,17 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
             for (int e = 0; e < 4; ++e) acc[i][j][e] = acc[i][j][e] > 0.f ? acc[i][j][e] : 0.f;
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      stamp();                                                   // [3]
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         store_block(i);
         PT_PIN_BLOCK(i);
       }
     }
-    stamp();                                                     // [4] stores issued
     if constexpr (EPI != EPI_STD) {
       if (grp == 1) __builtin_amdgcn_s_barrier();                // waves 4-7 fall one barrier behind again
     }
   }
-  if (grp == 0) __builtin_amdgcn_s_barrier();                    // balances the stagger barrier of waves 4-7
+  if (grp == 0) __builtin_amdgcn_s_barrier();                    // balances the extra barrier waves 4-7 took in the prologue
 }
 
 static int gr_num_cus = 0;
@@ -441,13 +425,9 @@ static int launch_row(const GemmBigArgs& a, hipStream_t s) {
   }
   const int ntiles = (a.M + 16 * MT - 1) / (16 * MT);
   const int grid = ntiles < gr_num_cus ? ntiles : gr_num_cus;
-  static int stagger_us = -1;
-  if (stagger_us < 0) { const char* e = getenv("PT_GEMM_STAGGER"); stagger_us = e ? atoi(e) : 0; }
-  GemmBigArgs b = a;
-  b.stagger = ((EPI == EPI_ADDLN || EPI == EPI_ADDLN_B) && ntiles > grid) ? stagger_us * 100 : 0;
   void* tok = nullptr;
   if (prof_is_on()) prof_record_begin(s, a.flops > 0 ? a.flops : 2.0 * a.M * a.N * a.K, 7, &tok);
-  PT_LAUNCH((gemm_row_kernel<MT, EPI>), dim3(grid), dim3(512), GR_SMEM, s, b, ntiles);
+  PT_LAUNCH((gemm_row_kernel<MT, EPI>), dim3(grid), dim3(512), GR_SMEM, s, a, ntiles);
   if (tok) prof_record_end(s, tok);
   return 0;
 }
@@ -460,8 +440,7 @@ int launch_gemm_row(const GemmBigArgs& a, hipStream_t s) {
     PT_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
     gr_num_cus = n > 0 ? n : 256;
   }
-  static int force_mt = -1;
-  if (force_mt < 0) { const char* e = getenv("PT_GEMM_ROW_MT"); force_mt = e ? atoi(e) : 0; }
+  const int force_mt = option(OPT_ROW_TILE);
   auto cost = [&](int bm) {
     const long tiles = (a.M + bm - 1) / bm;
     return ((tiles + gr_num_cus - 1) / gr_num_cus) * (long)bm;
@@ -473,7 +452,7 @@ int launch_gemm_row(const GemmBigArgs& a, hipStream_t s) {
     if ((a.M + 63) / 64 <= gr_num_cus) mt = 4;
     if ((a.M + 31) / 32 <= gr_num_cus) mt = 2;
   }
-  PT_CHECK(mt == 2 || mt == 4 || mt == 8 || mt == 10, "gemm_row: tile height 16*%d not built (PT_GEMM_ROW_MT = 2, 4, 8 or 10)", mt);
+  PT_CHECK(mt == 2 || mt == 4 || mt == 8 || mt == 10, "gemm_row: tile height 16*%d not built (option row_tile = 2, 4, 8 or 10)", mt);
 #define PT_ROW_DISPATCH(E)                                            \
   switch (mt) {                                                       \
     case 2: return launch_row<2, E>(a, s);                            \

@@ -117,11 +117,35 @@ struct GemmBigArgs {
   const float* gamma; const float* beta;
   const float* style; const int64_t* label; int n_label, rows_per_clip, n_classes;
   float* X;
-  int stagger;                        // start-time spread of the workgroups in 100 MHz ticks (0 = none), see launch_gemm8
-  unsigned long long* stamps;         // debug: per-workgroup phase timestamps (100 MHz), 64 per workgroup; normally null
   double flops;
 };
 int launch_gemm_big(const GemmBigArgs& a, hipStream_t s);
+
+// Fused tail of a decoder sub-layer (gemm_bf16_sub.hip): last Linear -> stylization pre-op -> style Linear -> residual +
+// post-LN -> optional next Linear, rows kept in registers between the products.
+struct SubArgs {
+  const unsigned short* A; int lda; int K1;        // sub-layer input rows [M, lda] bf16; K1 = 512 (out-proj) or 2048 (FFN-2)
+  const unsigned short* W1; const float* b1;       // [512][K1] bf16
+  const float* fold; const int64_t* label; int n_label, rows_per_clip, n_classes;   // folded style tables [classes][1024]
+  const unsigned short* W2p; const float* b2;      // style Linear [512][512], K axis permuted (launch_permute_k32)
+  const float* gamma; const float* beta;           // post-LN affine
+  unsigned short* X;                               // residual stream rows [M][512] bf16, updated in place
+  int M;
+};
+int launch_sublayer(const SubArgs& a, hipStream_t s);
+int sublayer_grid_limit();
+int launch_permute_k32(const unsigned short* in, unsigned short* out, int N, int K, hipStream_t s);
+
+// Run-time options: the library's only switches (pt_set_option / pt_get_option); nothing reads the environment.
+enum Option {
+  OPT_RESID_BF16,          // 1 (default): bf16 mode keeps the residual stream in bf16; 0: fp32 stream with a bf16 shadow
+  OPT_FUSED_TAIL,          // -1 (default): fused sub-layer tail where whole rounds of its grid pay; 0 never; 1 wherever it applies
+  OPT_SMALL_ROWS,          // rows up to which wide Linears (N != 512) take the 4-wave kernel (default 2048)
+  OPT_ROW_TILE,            // 0 (default): row kernel picks its tile height; 2 | 4 | 8 | 10 forces 16 x that many rows
+  OPT_ATTN_TRAIN_ROWWISE,  // 1: training attention on the row-wise kernels whatever the shape (default 0)
+  OPT_COUNT
+};
+int option(Option o);
 
 // layout
 int launch_ncl_to_cl(const float* in, float* out, int B, int C, int L, int ldo, int col_off, int zero_to, hipStream_t s);

@@ -779,7 +779,7 @@ int launch_attention_train_fwd(const float* Q, int ldq, const float* K, int ldk,
                                int Nq, int Nk, int H, float pdrop, unsigned long long seed, hipStream_t s) {
   PT_CHECK(Q && K && V && O && B > 0 && Nq > 0 && Nk > 0 && H > 0 && pdrop >= 0.f && pdrop < 1.f, "attention_train_fwd: bad argument");
   if (at_lds_bytes(Nq, Nk, false) <= 160 * 1024 && at_aligned(Q, ldq) && at_aligned(K, ldk) && at_aligned(V, ldv) &&
-      at_aligned(O, ldo) && !getenv("PT_ATTN_TRAIN_ROWWISE")) {
+      at_aligned(O, ldo) && option(OPT_ATTN_TRAIN_ROWWISE) == 0) {
     static bool attr = false;
     if (!attr) {
       PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -801,7 +801,7 @@ int launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const
   PT_CHECK(Q && K && V && dO && dQ && dK && dV && lse && delta && B > 0 && Nq > 0 && Nk > 0 && H > 0, "attention_bwd: bad argument");
   if (at_lds_bytes(Nq, Nk, true) <= 160 * 1024 && Nk <= 128 && at_aligned(Q, ldq) && at_aligned(K, ldk) && at_aligned(V, ldv) &&
       at_aligned(dO, ldo) && at_aligned(dQ, lddq) && at_aligned(dK, lddk) && at_aligned(dV, lddv) &&
-      !getenv("PT_ATTN_TRAIN_ROWWISE")) {
+      option(OPT_ATTN_TRAIN_ROWWISE) == 0) {
     static bool attr = false;
     if (!attr) {
       PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_tiled_kernel<2>),

@@ -39,6 +39,7 @@ struct StyleW {
   float* table = nullptr;   // [n_classes][1024]: scale | shift = emb_layers_2(SiLU(class_embed[c]))
   float* fold = nullptr;    // [n_classes][1024]: gamma*(1+scale) | beta*(1+scale)+shift (LayerNorm affine folded in; bf16 mode)
   LNW ln; DevConv out;
+  unsigned short* out_wp = nullptr;   // bf16 mode: out.wb with the K axis permuted for the fused tail (launch_permute_k32)
 };
 struct DecLayer {
   DevConv sa_in, sa_out, ca_q, ca_kv, ca_out, ff1, ff2;
@@ -142,7 +143,17 @@ static int pack_style(Model& m, const std::string& p, const std::string& class_e
       }
     if (upload_v(m, fold, &st.fold)) return 1;
   }
-  return pack_conv_public(m, st.out, p + "out_layers_2.2", "", "", false, false);
+  if (pack_conv_public(m, st.out, p + "out_layers_2.2", "", "", false, false)) return 1;
+  if (st.out.wb) {
+    PT_CHECK(st.out.Npad == DM && st.out.Kb == DM, "%sout_layers_2.2: expected a (%d,%d) Linear", p.c_str(), DM, DM);
+    void* wp = nullptr;
+    PT_HIP(hipMalloc(&wp, (size_t)DM * DM * 2));
+    m.allocs.push_back(wp);
+    st.out_wp = (unsigned short*)wp;
+    if (launch_permute_k32(st.out.wb, st.out_wp, DM, DM, nullptr)) return 1;
+    PT_HIP(hipStreamSynchronize(nullptr));
+  }
+  return 0;
 }
 
 static int pack_layer(Model& m, const std::string& p, const std::string& class_embed, int n_classes, DecLayer& L) {
@@ -265,9 +276,7 @@ static int lin_b(const DevConv& c, const bf16_t* A, int lda, int rows, float* C,
                  float slope, hipStream_t s, const double* pe = nullptr, int period = 0) {
   PT_CHECK(c.wb != nullptr, "bf16 weights were not packed for this layer");
   PT_CHECK(lda >= c.Kb, "lin_b: input leading dim %d < packed K %d", lda, c.Kb);
-  static int small_rows = -1;
-  if (small_rows < 0) { const char* e = getenv("PT_SMALLM_ROWS"); small_rows = e ? atoi(e) : 2048; }
-  const bool small = c.N != 512 && rows <= small_rows;     // few 256 x 256 tiles: the 4-wave kernel's smaller tiles fill more CUs
+  const bool small = c.N != 512 && rows <= option(OPT_SMALL_ROWS);     // few 256 x 256 tiles: the 4-wave kernel's smaller tiles fill more CUs
   if (!small && c.N >= 256 && c.N % 8 == 0 && (act == ACT_NONE || slope == 0.f)) {
     GemmBigArgs a;
     memset(&a, 0, sizeof(a));
@@ -294,18 +303,38 @@ static int lin_b(const DevConv& c, const bf16_t* A, int lda, int rows, float* C,
 // (x = LN(x + .), fp32 + bf16 copy).  The pre-LayerNorm activations never reach HBM.
 // bf16 mode, residual stream: x lives in bf16 only, so the ADDLN epilogue reads and writes 1 KB per row instead of
 // reading 2 KB and writing 3 KB (116 -> 81 us per launch at 75,776 rows; the rounding of x once per sub-layer moves the
-// logits' relative error from 5.9e-3 to 6.4e-3, tests/test_gpu_bf16.py).  PT_RESID_BF16=0 keeps the fp32 residual
-// stream with a bf16 shadow (A/B measurements).
-static bool resid_bf16() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PT_RESID_BF16"); v = e ? atoi(e) : 1; }
-  return v == 1;
+// logits' relative error from 5.9e-3 to 6.4e-3, tests/test_gpu_bf16.py).  Option resid_bf16 = 0 (pt_set_option) keeps the fp32
+// residual stream with a bf16 shadow (A/B measurements).
+static bool resid_bf16() { return option(OPT_RESID_BF16) == 1; }
+
+//
+// Where it pays, both launches become one (gemm_bf16_sub.hip: rows stay in registers between the two products).  That
+// kernel runs one 128-row tile per CU per round of its persistent grid, ~50 us a round at K1 = 512 whatever the fill, and
+// its epilogues are not hidden behind another wave's MFMAs, so it wins only when its last round is nearly full:
+// measured (tools/sublayer_bench.py, profiles/r2/sublayer_vs_two_launches.txt) 250 vs 305 us at 153,600 rows (4.7
+// rounds) but 143 vs 140 us at 75,776 (2.3 rounds) and 97 vs 74 us at 37,888 (1.2 rounds).  Rule: K1 = 512 and tiles
+// >= 85 % of the rounds they occupy (90 % at K1 = 2048, where it gains 4-11 %).  Option fused_tail = 0 / 1
+// (pt_set_option) forces it off / on (A/B measurements, tests).
+static bool use_fused_tail(const DevConv& last, const StyleW& st, int rows, int n_classes) {
+  if (!resid_bf16() || !st.out_wp || n_classes > 4 || last.Npad != DM || last.Kb % 32 != 0 || last.Kb < 64) return false;
+  const int mode = option(OPT_FUSED_TAIL);
+  if (mode >= 0) return mode == 1;
+  const long long tiles = (rows + 127) / 128, grid = sublayer_grid_limit(), rounds = (tiles + grid - 1) / grid;
+  return tiles * 100 >= rounds * grid * (last.Kb == DM ? 85 : 90);
 }
 
 static int sublayer_tail_b(const DevConv& last, const bf16_t* A, int lda, bf16_t* tmp, const StyleW& st, const LNW& ln,
                            float* x, bf16_t* xb, int rows, int rows_per_clip, const int64_t* label, int n_label,
                            int n_classes, hipStream_t s) {
   PT_CHECK(last.wb && st.out.wb && last.N == DM && st.out.N == DM && st.out.Kb == DM, "sublayer_tail: unexpected geometry");
+  if (use_fused_tail(last, st, rows, n_classes)) {
+    SubArgs f;
+    memset(&f, 0, sizeof(f));
+    f.A = A; f.lda = lda; f.K1 = last.Kb; f.W1 = last.wb; f.b1 = last.b; f.fold = st.fold;
+    f.label = label; f.n_label = n_label; f.rows_per_clip = rows_per_clip; f.n_classes = n_classes;
+    f.W2p = st.out_wp; f.b2 = st.out.b; f.gamma = ln.g; f.beta = ln.b; f.X = xb; f.M = rows;
+    return launch_sublayer(f, s);
+  }
   GemmBigArgs a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.W = last.wb; a.bias = last.b; a.M = rows; a.N = DM; a.K = last.Kb; a.Npad = last.Npad;

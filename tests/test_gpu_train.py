@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import probtalk_oracle_train as OT
+from probtalk_amd import _lib
 from probtalk_amd import train_ops as T
 from probtalk_amd import training
 from tests.helpers import GOLDEN, ref_state_dict, rel_err
@@ -207,14 +208,14 @@ def test_attention_tiled_matches_rowwise(B, Nq, Nk, p):
     res = []
     for rowwise in (False, True):
         if rowwise:
-            os.environ["PT_ATTN_TRAIN_ROWWISE"] = "1"
+            _lib.check(_lib.lib().pt_set_option(b"attn_train_rowwise", 1))
         try:
             qd, kvd = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
             o = T.Attention.apply(qd, kvd, 0, 0, 512, B, Nq, Nk, p, 99) if p > 0 else T.attention_cross(qd, kvd, B, Nq, Nk)
             o.backward(do)
             res.append((o.detach(), qd.grad, kvd.grad))
         finally:
-            os.environ.pop("PT_ATTN_TRAIN_ROWWISE", None)
+            _lib.check(_lib.lib().pt_set_option(b"attn_train_rowwise", 0))
     for a, b_ in zip(*res):
         assert rel_err(a.cpu(), b_.cpu()) < 1e-5
 
