@@ -30,6 +30,17 @@ class TrainWrapperBaseClass():
     def to_parallel(self):
         pass
 
+    def _sync_dropout(self, *modules):
+        """Wrappers with a `train_dropout` attribute (tests switch dropout off to compare with fixtures): every
+        nn.Dropout the module was built with p > 0 runs at that rate."""
+        import torch.nn as nn
+        for m in modules:
+            for sub in m.modules():
+                if isinstance(sub, nn.Dropout):
+                    if '_pt_p0' not in sub.__dict__:
+                        sub.__dict__['_pt_p0'] = sub.p
+                    sub.p = self.train_dropout if sub.__dict__['_pt_p0'] > 0 else 0.0
+
     def __call__(self, bat):
         raise NotImplementedError
 

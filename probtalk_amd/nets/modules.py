@@ -13,7 +13,10 @@ Reference classes mirrored (relative to /root/reference):
   nets/inpainting/gated_pixelcnn_1d.py:39-83       nets/inpainting/predictornet.py:13-112
   nets/inpainting/PTransformer.py:28-165,214-372,394-704
   nets/inpainting/RTransformer.py:181-230
-Eval (inference) mode only in this round: train-mode forward raises.
+In eval mode `forward`/`encode`/`decode`/... run the packed inference sequences of the library.  In train mode
+(`module.train()`) the same calls run the training kernels through `probtalk_amd.train_ops` autograd Functions
+(batch-statistic BatchNorm, Dropout, EMA codebook updates, straight-through estimator), so `loss.backward()` works on
+the module API as it does on the reference's modules (probtalk_amd/training.py holds the sequences).
 """
 import ctypes as C
 import math
@@ -27,10 +30,30 @@ from .. import _lib
 from .._lib import check, ptr, stream
 
 
-def _train_guard(mod, what):
-    if mod.training:
-        raise NotImplementedError(f"{what}: the training path is not built yet (call .eval()); "
-                                  "probtalk_amd has no PyTorch fallback")
+def _seeds_of(mod):
+    """The module's dropout seed stream (train_ops._Seeds); a wrapper may install a shared one as `_pt_seeds`."""
+    s = mod.__dict__.get("_pt_seeds")
+    if s is None:
+        from ..train_ops import _Seeds
+        s = mod.__dict__["_pt_seeds"] = _Seeds(0)
+    return s
+
+
+def _train_tensors(mod):
+    """name -> parameter / buffer for the training kernels, which read them in place: they must live on the GPU."""
+    from ..training import tensors_of
+    P = tensors_of(mod)
+    for k, v in P.items():
+        if not v.is_cuda:
+            raise RuntimeError(f"probtalk_amd: train mode reads the module's parameters in place; call .cuda() first "
+                               f"({type(mod).__name__}.{k} is on {v.device})")
+    return P
+
+
+def _cuda_keep_grad(t):
+    if not t.is_cuda:
+        raise RuntimeError("probtalk_amd: inputs must be CUDA (HIP) tensors")
+    return t.to(torch.float32)
 
 
 def _cuda_f32(t):
@@ -124,8 +147,9 @@ class _HandleOwner:
         return h
 
     def set_precision(self, precision):
-        """'fp32' (default, parity path) or 'bf16' (bf16 MFMA operands, fp32 accumulation; transformers keep an
-        fp32 residual stream and LayerNorm; the PQ-VAE keeps encode + nearest-code search in fp32)."""
+        """'fp32' (default, parity path) or 'bf16' (inference only: bf16 MFMA operands, fp32 accumulation and LayerNorm
+        statistics; the transformers' residual stream is bf16 too unless option resid_bf16 = 0; the PQ-VAE keeps
+        encode + nearest-code search in fp32).  Train mode always computes in fp32."""
         if precision not in ("fp32", "bf16"):
             raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
         if precision == "bf16" and not self._bf16_ok:
@@ -180,7 +204,8 @@ class _QuantizerBase(nn.Module):
 
 
 class ProductQuantization(_QuantizerBase):
-    """vqvae_modules.py:437-590, eval path."""
+    """vqvae_modules.py:437-590: eval path (indices in `.loss`) and train path (EMA update, commitment loss in `.loss`,
+    straight-through estimator)."""
 
     def __init__(self, embedding_dim, num_embeddings, commitment_cost, decay, epsilon=1e-5, num_chunks=8,
                  share_code=False, **kwargs):
@@ -206,11 +231,39 @@ class ProductQuantization(_QuantizerBase):
         return [f"embeddings_{i}" for i in range(self.num_chunks)]
 
     def forward(self, x, r=0., **kwargs):
-        _train_guard(self, "ProductQuantization.forward")
         if r != 0.:
-            raise NotImplementedError("random token replacement (r>0) is a training-time augmentation")
+            raise NotImplementedError("random token replacement (r>0) is off in every config of the path (vq.json)")
+        if self.training:
+            return self._forward_train(x)
         q, idx = self._search(x)
         return QuantizationOutput(q, idx)
+
+    def _forward_train(self, x):
+        """vqvae_modules.py:470-544: nearest codes, EMA codebook update with dead-code re-seeding (no gradient; the
+        returned codes are the OLD ones, as in the reference), commitment loss, straight-through estimator."""
+        from .. import train_ops as T
+        x = _cuda_keep_grad(x)
+        B, Cc, W = x.shape
+        G = self.num_chunks
+        if Cc != G * self.embedding_dim:
+            raise RuntimeError(f"quantizer: input has {Cc} channels, codebooks cover {G}x{self.embedding_dim}")
+        _train_tensors(self)
+        cb = torch.stack([getattr(self, n) for n in self._codebook_names()]).contiguous()
+        z = T.to_rows(x, Cc)
+        q, loss, idx = T.PQQuantizeTrain.apply(z, cb, self.commitment_cost)
+        cs = torch.stack([m.hidden for m in self.ema_cluster_size]).contiguous()
+        dw = torch.stack([m.hidden for m in self.ema_dw]).contiguous()
+        for m in list(self.ema_cluster_size) + list(self.ema_dw):
+            m.counter += 1
+        T.pq_ema_update(z.detach(), idx, cs, dw, cb, self.ema_dw[0].decay, self.epsilon, self.ema_dw[0].counter)
+        with torch.no_grad():
+            for i in range(G):
+                self.ema_cluster_size[i].hidden.copy_(cs[i])
+                self.ema_dw[i].hidden.copy_(dw[i])
+                getattr(self, f"embeddings_{i}").copy_(cb[i])
+        self.__dict__["_pt_cb"] = None
+        self.__dict__["_pt_last_indices"] = idx.view(B, W, G)        # not part of the reference's return value
+        return QuantizationOutput(T.RowsToNCL.apply(q, B, Cc, W), loss)
 
     def quantize_all(self, encoding_indices):
         """(..., G) int -> (..., G*D)  (vqvae_modules.py:557-564)."""
@@ -249,7 +302,8 @@ class ProductQuantization(_QuantizerBase):
 
 
 class VectorQuantizerEMA(_QuantizerBase):
-    """vqvae_modules.py:279-377, eval path (legacy single codebook)."""
+    """vqvae_modules.py:279-377 (legacy single codebook): eval -> (quantized, indices); train -> (quantized with the
+    straight-through estimator, commitment loss) after the EMA codebook update."""
 
     def __init__(self, embedding_dim, num_embeddings, commitment_cost, decay, epsilon=1e-5):
         super().__init__()
@@ -267,7 +321,19 @@ class VectorQuantizerEMA(_QuantizerBase):
         return ["embeddings"]
 
     def forward(self, x):
-        _train_guard(self, "VectorQuantizerEMA.forward")
+        if self.training:
+            from .. import train_ops as T
+            x = _cuda_keep_grad(x)
+            B, Cc, W = x.shape
+            _train_tensors(self)
+            z = T.to_rows(x, Cc)
+            q, loss, idx = T.PQQuantizeTrain.apply(z, self.embeddings.unsqueeze(0), self.commitment_cost)
+            self.ema_cluster_size.counter += 1
+            self.ema_dw.counter += 1
+            T.vq_ema_update(z.detach(), idx, self.ema_cluster_size.hidden, self.ema_dw.hidden, self.embeddings,
+                            self.ema_dw.decay, self.epsilon, self.ema_dw.counter)
+            self.__dict__["_pt_cb"] = None
+            return T.RowsToNCL.apply(q, B, Cc, W), loss
         q, idx = self._search(x)
         return q, idx.reshape(q.shape[0], q.shape[2])
 
@@ -325,8 +391,28 @@ class _VQBase(_HandleOwner, nn.Module):
             L = (L - 2) // 2 + 1
         return L
 
+    def _encode_train(self, x):
+        """Encoder in train mode (batch-statistic BatchNorm, running statistics updated): (B,C,T) -> z (B,emb,T')."""
+        from .. import train_ops as T, training
+        x = _cuda_keep_grad(x)
+        B, Cc, Tn = x.shape
+        if Cc != self.in_dim:
+            raise RuntimeError(f"expected {self.in_dim} pose channels, got {Cc}")
+        enc = training.encoder_sc_train if self._levels == 4 else training.legacy_encoder_train
+        z_rows, Tq = enc(_train_tensors(self), T.to_rows(x), B, Tn)
+        self.__dict__["_pt_handle"] = None          # BatchNorm statistics moved: the packed inference weights are stale
+        return T.RowsToNCL.apply(z_rows, B, self.embedding_dim, Tq)
+
+    def _decode_train(self, e):
+        from .. import train_ops as T, training
+        e = _cuda_keep_grad(e)
+        B, Cc, Tq = e.shape
+        dec = training.decoder_sc_train if self._levels == 4 else training.legacy_decoder_train
+        rows, Tout = dec(_train_tensors(self), T.to_rows(e, Cc), B, Tq)
+        self.__dict__["_pt_handle"] = None
+        return T.RowsToNCL.apply(rows, B, self.in_dim, Tout)
+
     def _encode_raw(self, x, want_z=True):
-        _train_guard(self, type(self).__name__ + ".encode")
         x = _cuda_f32(x)
         B, Cc, T = x.shape
         if Cc != self.in_dim:
@@ -344,7 +430,8 @@ class _VQBase(_HandleOwner, nn.Module):
         return z, q, idx
 
     def _decode_raw(self, e):
-        _train_guard(self, type(self).__name__ + ".decode")
+        if self.training:
+            return self._decode_train(e)
         e = _cuda_f32(e)
         B, Cc, Tq = e.shape
         h = self._handle()
@@ -357,7 +444,9 @@ class _VQBase(_HandleOwner, nn.Module):
 
     def decode_codes(self, codes):
         """quantize_all + transpose + decode in one call (predictor.py:439-442): codes (B,T',G) -> (B,C,8T')."""
-        _train_guard(self, type(self).__name__ + ".decode_codes")
+        if self.training:
+            q = self.vq_layer.quantize_all(codes)
+            return self._decode_train(q.reshape(codes.shape[0], codes.shape[1], -1).transpose(1, 2))
         if codes.dtype not in (torch.int32, torch.int64):
             codes = codes.to(torch.int64)
         codes = codes.contiguous()
@@ -373,7 +462,8 @@ class _VQBase(_HandleOwner, nn.Module):
 
 
 class VQVAE_SC(_VQBase):
-    """vqvae_1d_sc.py:277-324.  bf16 mode: the conv DECODER runs on bf16 MFMA; encode + code search stay fp32."""
+    """vqvae_1d_sc.py:277-324.  bf16 mode (inference): the conv DECODER runs on bf16 MFMA; encode + code search stay
+    fp32.  Train mode: encode / decode / forward(result_form='full') run the training kernels with autograd."""
     _kind = "vqvae_sc"
     _levels = 4
     _bf16_ok = True
@@ -403,7 +493,10 @@ class VQVAE_SC(_VQBase):
 
     def encode(self, gt_poses, r=0., **kwargs):
         if r != 0.:
-            raise NotImplementedError("random token replacement (r>0) is a training-time augmentation")
+            raise NotImplementedError("random token replacement (r>0) is off in every config of the path (vq.json)")
+        if self.training:
+            z = self._encode_train(gt_poses)
+            return z, self.vq_layer(z, r), {1: 0, 2: 0, 3: 0, 4: 0}
         z, q, idx = self._encode_raw(gt_poses)
         # the reference also returns the per-level encoder features; every caller zeroes or ignores them
         return z, QuantizationOutput(q, idx), {1: 0, 2: 0, 3: 0, 4: 0}
@@ -469,10 +562,15 @@ class VQVAE(_VQBase):
         return [self.in_dim, self.embedding_dim, self.num_embeddings, self.num_hiddens, 1, 3]
 
     def forward(self, gt_poses, id=None, pre_state=None, **kwargs):
+        if self.training:                                   # vqvae_1d.py:170-173 -> (e_q_loss, gt_recon)
+            e, e_q_loss = self.vq_layer(self._encode_train(gt_poses))
+            return e_q_loss, self._decode_train(e)
         _, e, _ = self._encode_raw(gt_poses, want_z=False)
         return e, self._decode_raw(e)
 
     def encode(self, gt_poses):
+        if self.training:
+            return self.vq_layer(self._encode_train(gt_poses))
         _, e, idx = self._encode_raw(gt_poses, want_z=False)
         return e, idx.reshape(idx.shape[0], idx.shape[1])
 
@@ -503,7 +601,14 @@ class ConditionEncoder(_HandleOwner, nn.Module):
         return [self.in_dim, self._num_hiddens]
 
     def forward(self, x):
-        _train_guard(self, "ConditionEncoder.forward")
+        if self.training:
+            from .. import train_ops as T, training
+            x = _cuda_keep_grad(x)
+            B, Cc, Tn = x.shape
+            rows, Tq = training.cond_encoder_train(_train_tensors(self), T.to_rows(x), B, Tn, self.feature_map[3].p,
+                                                   _seeds_of(self))
+            self.__dict__["_pt_handle"] = None
+            return T.RowsToNCL.apply(rows, B, self._num_hiddens, Tq)
         x = _cuda_f32(x)
         B, Cc, T = x.shape
         h = self._handle()

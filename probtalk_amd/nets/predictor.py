@@ -1,4 +1,4 @@
-"""`s2g_body_predictor` wrapper mirror (nets/inpainting/predictor.py:27-686), inference side."""
+"""`s2g_body_predictor` wrapper mirror (nets/inpainting/predictor.py:27-686): training step and inference."""
 import time
 
 import numpy as np
@@ -61,7 +61,9 @@ class TrainWrapper(TrainWrapperBaseClass):
         for i in range(self.random_mask.shape[0]):
             self.random_mask[i, 0, i:(i + 30)] = 1
         self.train_dropout = 0.1                                        # nn.TransformerDecoderLayer / ConditionEncoder dp
-        self._seeds = train_ops._Seeds(0)
+        # dropout seed stream of the training step.  Each rank draws its own masks; the position in the stream is checkpointed.
+        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+        self._seeds = train_ops._Seeds(rank)
         super().__init__(args, config)
 
     def to_parallel(self):
@@ -76,7 +78,8 @@ class TrainWrapper(TrainWrapperBaseClass):
 
     def state_dict(self):
         return {'AudEnc': self.AudEnc.state_dict(), 'Predictor': self.Predictor.state_dict(),
-                'TextEnc': self.TextEnc.state_dict(), 'generator_optim': self.generator_optimizer.state_dict()}
+                'TextEnc': self.TextEnc.state_dict(), 'generator_optim': self.generator_optimizer.state_dict(),
+                'dropout_seeds': self._seeds.state_dict()}      # extra key: the reference's loader reads by name
 
     def load_state_dict(self, state_dict):
         def strip(d):
@@ -89,6 +92,8 @@ class TrainWrapper(TrainWrapperBaseClass):
             self.TextEnc.load_state_dict(strip(state_dict['TextEnc']))
         if 'generator_optim' in state_dict:
             self.generator_optimizer.load_state_dict(state_dict['generator_optim'])
+        if 'dropout_seeds' in state_dict:
+            self._seeds.load_state_dict(state_dict['dropout_seeds'])
 
     def __call__(self, bat):
         """One training step (predictor.py:168-280): frozen PQ-VAE codes as targets, AudEnc + PredictorNet forward in
@@ -131,12 +136,17 @@ class TrainWrapper(TrainWrapperBaseClass):
             if next(m.parameters()).device.type != 'cuda':
                 m.cuda()
             m.train()
-        Pa, Pp = training.tensors_of(self.AudEnc), training.tensors_of(self.Predictor)
-        N = state.shape[1] * state.shape[2]
-        keep_scores = bat['_keep_scores'].to(dev) if '_keep_scores' in bat else torch.rand(bs, N, device=dev)
+        self._sync_dropout(self.AudEnc, self.Predictor)
+        # one dropout seed stream for the step, consumed in call order (AudEnc, then the decoder layers)
+        self.AudEnc.__dict__['_pt_seeds'] = self.Predictor.__dict__['_pt_seeds'] = self._seeds
+        if '_keep_scores' in bat:
+            self.Predictor.decoder.__dict__['_pt_keep_scores'] = bat['_keep_scores'].to(dev)
         self.generator_optimizer.zero_grad()
-        loss, _ = training.predictor_loss(Pa, Pp, aud, input_poses, mask, id.reshape(-1), state, keep_scores, epoch_ratio,
-                                          p_drop=self.train_dropout, seeds=self._seeds, groups=self.config.Model.groups)
+        audio = self.AudEnc(aud)                                                            # predictor.py:243
+        pred_state = self.Predictor(input_poses, state, mask, id.reshape(-1), audio, None, epoch_ratio)   # :254
+        logits = pred_state['logits']
+        loss = train_ops.CrossEntropy.apply(logits.reshape(-1, logits.shape[-1]).contiguous(),
+                                            state.reshape(-1).to(torch.int64).contiguous())   # :261
         pa, pp = list(self.AudEnc.parameters()), list(self.Predictor.parameters())
         multi = torch.distributed.is_available() and torch.distributed.is_initialized() \
             and torch.distributed.get_world_size() > 1

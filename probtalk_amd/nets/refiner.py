@@ -57,7 +57,8 @@ class TrainWrapper(TrainWrapperBaseClass):
         for i in range(self.random_mask.shape[0]):
             self.random_mask[i, 0, i:(i + 30)] = 1
         self.train_dropout = 0.1
-        self._seeds = train_ops._Seeds(1)
+        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+        self._seeds = train_ops._Seeds(1 + 2 * rank)              # per-rank dropout masks; position checkpointed
         super().__init__(args, config)
 
     def to_parallel(self):
@@ -70,7 +71,7 @@ class TrainWrapper(TrainWrapperBaseClass):
 
     def state_dict(self):
         return {'HFTransformer': self.RTransformer.state_dict(), 'AudEnc': self.AudEnc.state_dict(),
-                'generator_optim': self.generator_optimizer.state_dict()}
+                'generator_optim': self.generator_optimizer.state_dict(), 'dropout_seeds': self._seeds.state_dict()}
 
     def load_state_dict(self, state_dict):
         def strip(d):
@@ -81,6 +82,8 @@ class TrainWrapper(TrainWrapperBaseClass):
             self.AudEnc.load_state_dict(strip(state_dict['AudEnc']))
         if 'generator_optim' in state_dict:
             self.generator_optimizer.load_state_dict(state_dict['generator_optim'])
+        if 'dropout_seeds' in state_dict:
+            self._seeds.load_state_dict(state_dict['dropout_seeds'])
 
     def __call__(self, bat):
         """One refiner training step (refiner.py:183-311) on the HIP training kernels: frozen PQ-VAE reconstruction of
@@ -118,10 +121,13 @@ class TrainWrapper(TrainWrapperBaseClass):
         if next(rt.parameters()).device.type != 'cuda':
             rt.cuda()
         rt.train()
-        P = training.tensors_of(rt)
+        self._sync_dropout(rt)
+        rt.__dict__['_pt_seeds'] = self._seeds
         self.generator_optimizer.zero_grad()
-        loss, sums, _ = training.refiner_loss(P, aud, input_poses, gt_poses, mask, id.reshape(-1), p_drop=self.train_dropout,
-                                              seeds=self._seeds)
+        pred_poses = rt(input_poses, aud, mask, id.reshape(-1))                              # refiner.py:296
+        nmask = (1.0 - mask).reshape(-1).contiguous()
+        loss, sums = train_ops.MaskedL1Losses.apply(train_ops.to_rows(pred_poses), train_ops.ncl_to_rows(gt_poses), nmask,
+                                                    float(nmask.sum()), bs, t, [0, 6, 96, 276, 376], [0.25] * 4, 276)   # :297
         params = list(rt.parameters())
         multi = torch.distributed.is_available() and torch.distributed.is_initialized() \
             and torch.distributed.get_world_size() > 1

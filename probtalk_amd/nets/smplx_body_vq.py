@@ -80,19 +80,14 @@ class TrainWrapper(TrainWrapperBaseClass):
         if next(model.parameters()).device.type != 'cuda':
             model.cuda()
         model.train()
-        P = training.tensors_of(model)
-        ql = model.vq_layer
         gt_rows = train_ops.ncl_to_rows(gt)
         optimizer.zero_grad()
-        z, e_q_loss, idx, pred, t_out = training.legacy_vq_train_forward(P, ql.embeddings, gt_rows, bs, t, ql.commitment_cost)
-        if t_out != t:
-            raise RuntimeError(f"legacy VQ-VAE training needs T divisible by 4 (got {t}: decoder returns {t_out})")
-        # EMA codebook update (no gradient); the decoder above used the OLD codes, as the reference does (323-334)
-        ql.ema_cluster_size.counter += 1
-        ql.ema_dw.counter += 1
-        train_ops.vq_ema_update(z.detach(), idx, ql.ema_cluster_size.hidden, ql.ema_dw.hidden, ql.embeddings, ql.ema_dw.decay,
-                                ql.epsilon, ql.ema_dw.counter)
-        ql.__dict__['_pt_cb'] = None
+        # smplx_body_vq.py:139: encoder, quantizer (EMA codebook update inside, no re-seeding; the decoder sees the OLD
+        # codes, vqvae_modules.py:323-334), decoder
+        e_q_loss, gt_recon = model(gt)
+        if gt_recon.shape[2] != t:
+            raise RuntimeError(f"legacy VQ-VAE training needs T divisible by 4 (got {t}: decoder returns {gt_recon.shape[2]})")
+        pred = train_ops.to_rows(gt_recon)
         ones = torch.ones(bs * t, device=gt.device)
         rec, sums = train_ops.MaskedL1Losses.apply(pred, gt_rows, ones, float(bs * t), bs, t, [0, n], [1.0], n)
         loss = rec + e_q_loss

@@ -9,8 +9,12 @@ Reference classes mirrored (relative to /root/reference):
   nets/inpainting/PTransformer.py:394-704        PTransformer (tokens_to_logits, sample_good)
   nets/inpainting/RTransformer.py:181-230        RTransformer
 The torch sub-modules are parameter containers (same state_dict keys as the reference); compute
-goes through the C ABI.  Eval mode only in this round.
+goes through the C ABI.  Eval mode runs the packed inference sequences (MaskGIT sampling, refiner forward); train mode
+(`.train()`) runs the training kernels through `probtalk_amd.train_ops` autograd Functions, so the reference's training
+calls (`self.Predictor(input_poses, state, mask, id, audio, text, epoch_ratio)` -> {"logits": ...}, predictor.py:254;
+`self.RTransformer(input_poses, aud, mask, id)`, refiner.py:296) work on the module API.
 """
+import math
 import os
 
 import numpy as np
@@ -20,7 +24,7 @@ from torch.nn.init import xavier_uniform_
 
 from .. import _lib
 from .._lib import check, ptr, stream
-from .modules import _HandleOwner, _cuda_f32, _train_guard
+from .modules import _HandleOwner, _cuda_f32, _cuda_keep_grad, _seeds_of, _train_tensors
 
 
 def zero_module(module):
@@ -139,7 +143,9 @@ class PTransformer(nn.Module):
 
     def tokens_to_logits(self, x, label, condition):
         """x (B,T',G) int (mask id = num_code), label (B,), condition (B,768,T') -> (B,T',G,num_code)."""
-        _train_guard(self, "PTransformer.tokens_to_logits")
+        if self.training:
+            raise RuntimeError("tokens_to_logits is the inference entry (no dropout, no autograd): call .eval() first, or "
+                               "use forward(x, label, condition, input_codes, epoch_ratio) to train")
         cond = _cuda_f32(condition)
         B, _, Tq = cond.shape
         ids = x.to(device=cond.device, dtype=torch.int32).contiguous()
@@ -166,7 +172,8 @@ class PTransformer(nn.Module):
         each pass, PTransformer.py:697-698).  A one-element int64 CUDA tensor as `seed` is read by the kernels at run
         time: nothing of the call depends on a host value then, so it can be captured into a HIP graph and replayed with a
         new seed written to that tensor (probtalk_amd/graphs.py)."""
-        _train_guard(self, "PTransformer.sample_good")
+        if self.training:
+            raise RuntimeError("sample_good is the inference entry (the reference calls it under eval()): call .eval() first")
         if mode != "cosine":
             raise NotImplementedError("sample_good is only called with the cosine schedule")
         cond = _cuda_f32(condition)
@@ -196,8 +203,44 @@ class PTransformer(nn.Module):
                                         ptr(ws), ws.numel(), stream()))
         return (codes, logits) if return_logits else codes
 
+    def gamma(self, r):
+        """PTransformer.py:437,578-580: the 'linear' schedule, share of tokens left unmasked."""
+        return 1 - r
+
+    def random_token(self, state, type, epoch_ratio, keep_scores=None):
+        """PTransformer.py:559-576 ('mask'): keep r = floor(gamma(ratio) * N) random tokens per clip, the rest become the
+        mask id.  keep_scores (B, N) stands in for torch.rand (tests)."""
+        if type != 'mask':
+            raise NotImplementedError("only the 'mask' replacement is used on the maskgit path")
+        B = state.shape[0]
+        flat = state.reshape(B, -1)
+        r = math.floor(self.gamma(epoch_ratio) * flat.shape[1])
+        if keep_scores is None:
+            keep_scores = torch.rand(flat.shape, device=flat.device)
+        keep = torch.zeros_like(flat, dtype=torch.bool)
+        if r > 0:
+            keep.scatter_(1, keep_scores.topk(r, dim=1).indices, True)
+        return torch.where(keep, flat, torch.full_like(flat, self.mask_id)).reshape(state.shape)
+
+    def _forward_rows(self, x, label, cond_rows, B, Tq, epoch_ratio):
+        from .. import training
+        owner = self._owner()
+        ids = self.random_token(x, 'mask', epoch_ratio, self.__dict__.pop("_pt_keep_scores", None))
+        p_drop = self.transformer_decoder.layers[0].dropout.p
+        lab = label.to(device=cond_rows.device, dtype=torch.int64).contiguous().reshape(-1)
+        rows = training.ptransformer_train(_train_tensors(owner), ids, lab, cond_rows, B, Tq, self.groups, p_drop,
+                                           _seeds_of(owner))
+        owner.__dict__["_pt_handle"] = None         # parameters are about to move: the packed inference weights are stale
+        return {"logits": rows[:, :self.num_code].reshape(B, Tq, self.groups, self.num_code)}
+
     def forward(self, x, label, condition, input_codes, epoch_ratio):
-        raise NotImplementedError("PTransformer.forward is the training path (not built yet)")
+        """PTransformer.py:443-504 (training): x (B,T',G) code indices, condition (B,768,T') -> {"logits": (B,T',G,num_code)}."""
+        if input_codes is not None:
+            raise NotImplementedError("input_codes (motion_block) is not on the configured path")
+        from .. import train_ops as T
+        cond = _cuda_keep_grad(condition)
+        B, Cc, Tq = cond.shape
+        return self._forward_rows(x, label, T.to_rows(cond, Cc), B, Tq, epoch_ratio)
 
 
 class PredictorNet(_HandleOwner, nn.Module):
@@ -250,8 +293,7 @@ class PredictorNet(_HandleOwner, nn.Module):
                 self.decoder.condi_dim - 512]
 
     def condition(self, masked_motion, mask, audio):
-        """The part of forward before the decoder call (predictornet.py:87-100): (B,768,T')."""
-        _train_guard(self, "PredictorNet.forward")
+        """The part of forward before the decoder call (predictornet.py:87-100): (B,768,T') (inference sequence)."""
         mm, mk, au = _cuda_f32(masked_motion), _cuda_f32(mask), _cuda_f32(audio)
         B, Cc, T = mm.shape
         if Cc != self.mot_dim or tuple(mk.shape) != (B, 1, T):
@@ -271,9 +313,19 @@ class PredictorNet(_HandleOwner, nn.Module):
 
     def forward(self, masked_motion, state, mask, label, audio, text, epoch_ratio, input_codes=None,
                 distribution=False, noise=None, seed=None):
-        _train_guard(self, "PredictorNet.forward")
         if distribution:
             raise NotImplementedError("distribution=True calls a method the reference does not define")
+        if self.training:
+            # predictornet.py:87-103: motion-context encoder, cat with the audio features, decoder(state, ...) -> logits
+            from .. import train_ops as T, training
+            mm, mk, au = _cuda_keep_grad(masked_motion), _cuda_keep_grad(mask), _cuda_keep_grad(audio)
+            B, _, Tn = mm.shape
+            motion, Tq = training.motion_context_train(_train_tensors(self), T.to_rows(torch.cat([mm, mk], dim=1)), B, Tn)
+            if tuple(au.shape) != (B, self.decoder.condi_dim - 512, Tq):
+                raise RuntimeError(f"PredictorNet: audio features must be (B,{self.decoder.condi_dim - 512},{Tq}), "
+                                   f"got {tuple(au.shape)}")
+            cond = torch.cat([motion, T.to_rows(au, au.shape[1])], dim=1).contiguous()
+            return self.decoder._forward_rows(state, label, cond, B, Tq, epoch_ratio)
         cond = self.condition(masked_motion, mask, audio)
         return self.decoder.sample_good(label, cond, input_codes, T=self.T, noise=noise, seed=seed)
 
@@ -307,7 +359,17 @@ class RTransformer(_HandleOwner, nn.Module):
         return [self.input_dim, self.cond_dim, self.n_classes, self.num_hidden_layers]
 
     def forward(self, x, condition, mask, label):
-        _train_guard(self, "RTransformer.forward")
+        if self.training:
+            # RTransformer.py:209-230 in train mode (dropout 0.1 in every decoder layer)
+            from .. import train_ops as T, training
+            xg, cg, mg = _cuda_keep_grad(x), _cuda_keep_grad(condition), _cuda_keep_grad(mask)
+            B, Cc, Tn = xg.shape
+            cond_rows = T.to_rows(torch.cat([cg, 1.0 - mg, mg], dim=1))       # F.one_hot(mask, 2): [mask==0 | mask==1]
+            lab = label.to(device=xg.device, dtype=torch.int64).contiguous().reshape(-1)
+            rows = training.rtransformer_train(_train_tensors(self), T.to_rows(xg), cond_rows, lab, B, Tn,
+                                               self.transformer_decoder.layers[0].dropout.p, _seeds_of(self))
+            self.__dict__["_pt_handle"] = None
+            return T.RowsToNCL.apply(rows, B, self.input_dim, Tn)
         x, cond, mk = _cuda_f32(x), _cuda_f32(condition), _cuda_f32(mask)
         B, Cc, T = x.shape
         if Cc != self.input_dim or tuple(cond.shape) != (B, self.cond_dim, T) or tuple(mk.shape) != (B, 1, T):

@@ -84,26 +84,14 @@ class TrainWrapper(TrainWrapperBaseClass):
         if next(vq.parameters()).device.type != 'cuda':
             vq.cuda()
         vq.train()
-        P = training.tensors_of(vq)
-        ql = vq.vq_layer
-        G = ql.num_chunks
-        cb = torch.stack([getattr(ql, f'embeddings_{i}') for i in range(G)]).contiguous()
         gt_rows = train_ops.ncl_to_rows(gt_poses)
         self.generator_optimizer.zero_grad()
-        z, e_q_loss, idx, pred, t_out = training.vqvae_train_forward(P, cb, gt_rows, bs, t, ql.commitment_cost)
-        if t_out != t:
-            raise RuntimeError(f"PQ-VAE training needs T divisible by 8 (got {t}: decoder returns {t_out})")
-        # EMA codebook update (no gradient); the decoder above used the OLD codes, as the reference does
-        cs = torch.stack([m.hidden for m in ql.ema_cluster_size]).contiguous()
-        dw = torch.stack([m.hidden for m in ql.ema_dw]).contiguous()
-        for m in list(ql.ema_cluster_size) + list(ql.ema_dw):
-            m.counter += 1
-        train_ops.pq_ema_update(z.detach(), idx, cs, dw, cb, ql.ema_dw[0].decay, ql.epsilon, ql.ema_dw[0].counter)
-        for i in range(G):
-            ql.ema_cluster_size[i].hidden.copy_(cs[i])
-            ql.ema_dw[i].hidden.copy_(dw[i])
-            getattr(ql, f'embeddings_{i}').copy_(cb[i])
-        ql.__dict__['_pt_cb'] = None
+        # vq_teacher.py:160: encoder, quantizer (EMA codebook update inside; the decoder sees the OLD codes), decoder
+        z, qo, pred_poses = vq(gt_poses=gt_poses, result_form='full')
+        e_q_loss = qo.loss
+        if pred_poses.shape[2] != t:
+            raise RuntimeError(f"PQ-VAE training needs T divisible by 8 (got {t}: decoder returns {pred_poses.shape[2]})")
+        pred = train_ops.to_rows(pred_poses)
         bounds, weights, names = self._loss_spec()
         vel_cols = n - self.each_dim[3]
         rec, sums = train_ops.VQLosses.apply(pred, gt_rows, bs, t, bounds, weights, vel_cols, 0.01)

@@ -362,6 +362,12 @@ class _Seeds:
         self.n += 1
         return (self.base << 20) + self.n
 
+    def state_dict(self):
+        return {"base": self.base, "n": self.n}
+
+    def load_state_dict(self, sd):
+        self.base, self.n = int(sd["base"]), int(sd["n"])
+
 
 def dropout(x, p, seeds):
     if p <= 0.0 or seeds is None:
@@ -377,6 +383,52 @@ def ncl_to_rows(x_ncl, width=None):
     out = _empty(B * Ln, ld)
     check(L.pt_ncl_to_cl(ptr(x_ncl.contiguous()), ptr(out), B, C, Ln, ld, stream()))
     return out
+
+
+class NCLToRows(torch.autograd.Function):
+    """(B, C, L) -> rows [B*L, ld] (pad columns zero) with a gradient: the module API's tensors are channels-first, the
+    kernels' are channels-last rows."""
+
+    @staticmethod
+    def forward(ctx, x, ld):
+        B, C, Ln = x.shape
+        out = _empty(B * Ln, ld)
+        check(_lib.lib().pt_ncl_to_cl(ptr(x.contiguous()), ptr(out), B, C, Ln, ld, stream()))
+        ctx.meta = (B, C, Ln, ld)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, Ln, ld = ctx.meta
+        dx = _empty(B, C, Ln)
+        check(_lib.lib().pt_cl_to_ncl(ptr(dy.contiguous()), ld, ptr(dx), B, C, Ln, stream()))
+        return dx, None
+
+
+class RowsToNCL(torch.autograd.Function):
+    """rows [B*L, ld] -> (B, C, L) (the first C columns) with a gradient."""
+
+    @staticmethod
+    def forward(ctx, rows, B, C, Ln):
+        out = _empty(B, C, Ln)
+        ld = rows.shape[1]
+        check(_lib.lib().pt_cl_to_ncl(ptr(rows.contiguous()), ld, ptr(out), B, C, Ln, stream()))
+        ctx.meta = (B, C, Ln, ld)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, Ln, ld = ctx.meta
+        d = _empty(B * Ln, ld)
+        check(_lib.lib().pt_ncl_to_cl(ptr(dy.contiguous()), ptr(d), B, C, Ln, ld, stream()))
+        return d, None, None, None
+
+
+def to_rows(x_ncl, width=None):
+    """ncl_to_rows for tensors that may carry a gradient."""
+    ld = width or _ru(x_ncl.shape[1], 32)
+    x = x_ncl.to(torch.float32)
+    return NCLToRows.apply(x, ld) if x.requires_grad else ncl_to_rows(x, ld)
 
 
 class PQQuantizeTrain(torch.autograd.Function):

@@ -198,25 +198,34 @@ def vqvae_train_forward(P, codebooks, x_rows, B, Tn, commitment_cost=0.25):
 
 
 # ------------------------------------------------------------------------------------------- legacy VQ-VAE (s2g_body_vq)
-def legacy_vq_train_forward(P, codebook, x_rows, B, Tn, commitment_cost=0.25):
-    """VQVAE.forward in train mode (nets/spg/vqvae_1d.py:66-92,115-144,163-173) without the EMA side effect: encoder with
-    two stride-2 stages, single-codebook nearest-code search + commitment loss + straight-through estimator
-    (VectorQuantizerEMA, vqvae_modules.py:309-348), decoder.  -> (z rows, commitment loss, indices, pred rows, T_out)."""
-    p = "encoder."
+def legacy_encoder_train(P, x_rows, B, Tn, p="encoder."):
+    """Legacy Encoder.forward (nets/spg/vqvae_1d.py:66-92) in train mode: two stride-2 stages -> (z rows, T/4)."""
     h, L = _cnr(P, p + "project.", x_rows, B, Tn)
     h = _res_stack(P, p + "_enc_1.", h, B, L)
     for i in (1, 2):
         h, L = _cnr(P, f"{p}_down_{i}.", h, B, L, "down", True)
         h = _res_stack(P, f"{p}_enc_{i + 1}.", h, B, L)
-    z = T.conv(h, P[p + "pre_vq_conv.weight"], P[p + "pre_vq_conv.bias"], 0, B, L)
-    q, e_q_loss, idx = T.PQQuantizeTrain.apply(z, codebook.unsqueeze(0), commitment_cost)
-    p = "decoder."
-    h = T.conv(q, P[p + "aft_vq_conv.weight"], P[p + "aft_vq_conv.bias"], 0, B, L)
+    return T.conv(h, P[p + "pre_vq_conv.weight"], P[p + "pre_vq_conv.bias"], 0, B, L), L
+
+
+def legacy_decoder_train(P, q_rows, B, L, p="decoder."):
+    """Legacy Decoder.forward (nets/spg/vqvae_1d.py:115-144) in train mode -> (pred rows, 4 T')."""
+    h = T.conv(q_rows, P[p + "aft_vq_conv.weight"], P[p + "aft_vq_conv.bias"], 0, B, L)
     h = _res_stack(P, p + "_dec_1.", h, B, L)
     for i in (2, 3):
         h, L = _cnr(P, f"{p}_up_{i}.", h, B, L, "up", True)
         h = _res_stack(P, f"{p}_dec_{i}.", h, B, L)
-    return z, e_q_loss, idx, T.conv(h, P[p + "project.weight"], P[p + "project.bias"], 0, B, L), L
+    return T.conv(h, P[p + "project.weight"], P[p + "project.bias"], 0, B, L), L
+
+
+def legacy_vq_train_forward(P, codebook, x_rows, B, Tn, commitment_cost=0.25):
+    """VQVAE.forward in train mode (nets/spg/vqvae_1d.py:163-173) without the EMA side effect: encoder, single-codebook
+    nearest-code search + commitment loss + straight-through estimator (VectorQuantizerEMA, vqvae_modules.py:309-348),
+    decoder.  -> (z rows, commitment loss, indices, pred rows, T_out)."""
+    z, L = legacy_encoder_train(P, x_rows, B, Tn)
+    q, e_q_loss, idx = T.PQQuantizeTrain.apply(z, codebook.unsqueeze(0), commitment_cost)
+    pred, L = legacy_decoder_train(P, q, B, L)
+    return z, e_q_loss, idx, pred, L
 
 
 # ------------------------------------------------------------------------------------------- refiner

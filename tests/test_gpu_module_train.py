@@ -1,0 +1,226 @@
+"""GPU: the nn.Module API in train mode.  Each hot-path module is put in `.train()`, called the way the reference's
+wrappers call it (predictor.py:243,254; vq_teacher.py:160; smplx_body_vq.py:139; refiner.py:296), back-propagated
+through, and compared with the fixtures the imported reference produced (tests/golden/*_train_*.npz, tools/make_golden_*):
+loss, reconstruction, a selection of gradients, EMA codebook state and BatchNorm running statistics.  Dropout is set to 0
+on the modules (the fixtures were made that way: the reference's dropout masks come from torch's RNG); a last test runs
+with dropout on and checks the masks are replayed in backward (finite, repeatable from the seed stream)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from probtalk_amd import train_ops as T
+from tests.helpers import (GOLDEN, LEGACY_VQ_TRAIN_GRAD_KEYS, REFINER_TRAIN_GRAD_KEYS, TRAIN_GRAD_KEYS, VQ_TRAIN_GRAD_KEYS,
+                           ref_state_dict, refiner_train_case, rel_err)
+
+pytestmark = pytest.mark.gpu
+# the per-tensor bound the functional-path tests use when a (Leaky)ReLU unit within fp32 rounding of 0 fell on the other
+# side than in the reference (tests/test_gpu_train.py, tests/test_gpu_vq_train.py prove those cases unit by unit)
+GRAD_TOL = 5e-2
+
+
+def _gold(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, name)).items()}
+
+
+def _no_dropout(*mods):
+    for m in mods:
+        for sub in m.modules():
+            if isinstance(sub, nn.Dropout):
+                sub.p = 0.0
+
+
+def _check_grads(named, keys, gold, head, what):
+    gmax = max(float(np.abs(gold[f"grad_{i}"]).max()) for i in range(len(keys)))
+    num = den = 0.0
+    for i, k in enumerate(keys):
+        p = named(k)
+        ref = gold[f"grad_{i}"]
+        if float(ref.abs().max()) < 1e-6 * gmax:          # conv bias in front of a batch-statistic BatchNorm: exactly 0
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-5 * gmax, k
+            continue
+        assert p.grad is not None, f"{what}: no gradient reached {k}"
+        got = p.grad.cpu()
+        got = got[:head] if got.numel() > 20000 else got
+        assert rel_err(got, ref) < GRAD_TOL, (what, k)
+        num += float((got.double() - ref.double()).pow(2).sum())
+        den += float(ref.double().pow(2).sum())
+    assert math.sqrt(num / den) < 5e-3, (what, math.sqrt(num / den))
+
+
+def test_predictor_modules_train_forward_backward_match_reference_fixture():
+    from probtalk_amd.nets.modules import ConditionEncoder
+    from probtalk_amd.nets.transformer_modules import PredictorNet
+    from tests.test_oracle_train_golden import train_case
+    aud, inp, mask, label, state, keep, ratio = train_case()
+    ae = ConditionEncoder(768, 256, 2, 256)
+    pn = PredictorNet(False, 376, 128, 512, 10, 6, 4, groups=4, identity=True, maskgit=True, maskgit_T=8,
+                      transformer=True, text=None, audio="wav2vec", motion_context=True)
+    ae.load_state_dict(ref_state_dict("AudEnc"))
+    pn.load_state_dict(ref_state_dict("Predictor"))
+    ae.cuda().train()
+    pn.cuda().train()
+    _no_dropout(ae, pn)
+    pn.decoder.__dict__["_pt_keep_scores"] = keep.cuda()         # stands in for random_token's torch.rand
+    audio = ae(aud.cuda())                                        # predictor.py:243
+    assert audio.requires_grad and tuple(audio.shape) == (2, 256, 11)
+    out = pn(inp.cuda(), state.cuda(), mask.cuda(), label.cuda(), audio, None, ratio)       # predictor.py:254
+    assert set(out) == {"logits"} and tuple(out["logits"].shape) == (2, 11, 4, 128)
+    logits = out["logits"]
+    loss = T.CrossEntropy.apply(logits.reshape(-1, 128).contiguous(), state.reshape(-1).to(torch.int64).cuda())
+    loss.backward()
+    gold = _gold("predictor_train_b2_t88.npz")
+    assert abs(float(loss) - float(gold["loss"])) < 1e-5 * abs(float(gold["loss"]))
+    pa, pp = dict(ae.named_parameters()), dict(pn.named_parameters())
+    _check_grads(lambda key: (pa if key[0] == "AudEnc" else pp)[key[1]], TRAIN_GRAD_KEYS, gold, 8, "predictor")
+    # the decoder alone, as PTransformer.forward (PTransformer.py:443): condition (B,768,T') in, same logits out
+    pn.zero_grad()
+    cond = torch.randn(2, 768, 11, device="cuda", requires_grad=True)
+    pn.decoder.__dict__["_pt_keep_scores"] = keep.cuda()
+    lg = pn.decoder(state.cuda(), label.cuda(), cond, None, ratio)["logits"]
+    lg.square().mean().backward()
+    assert cond.grad is not None and bool(torch.isfinite(cond.grad).all()) and float(cond.grad.abs().max()) > 0
+    # inference entries refuse train mode instead of silently running without dropout
+    with pytest.raises(RuntimeError):
+        pn.decoder.sample_good(label.cuda(), cond.detach(), None)
+    # eval() after a train step repacks the (unchanged) weights and infers
+    pn.eval()
+    codes = pn(inp.cuda(), None, mask.cuda(), label.cuda(), audio.detach(), None, 1, seed=3)
+    assert tuple(codes.shape) == (2, 11, 4) and int(codes.max()) < 128
+
+
+def test_vqvae_sc_train_forward_backward_matches_reference_fixture():
+    from probtalk_amd.nets.modules import VQVAE_SC
+    from tests.test_oracle_vq_train_golden import load_gold, vq_train_case
+    vq = VQVAE_SC(376, 512, 128, 1024, 2, 512, q_type="pro", groups=4)
+    vq.load_state_dict(ref_state_dict("VQ"))
+    vq.cuda().train()
+    x = vq_train_case().cuda()
+    B, _, Tn = x.shape
+    z, qo, pred = vq(gt_poses=x, result_form="full")              # vq_teacher.py:160
+    assert tuple(z.shape) == (B, 512, Tn // 8) and tuple(pred.shape) == (B, 376, Tn)
+    assert qo.quantized.requires_grad and qo.loss.dim() == 0     # train mode: the commitment loss travels in `.loss`
+    x_rows = T.ncl_to_rows(x)
+    rec, sums = T.VQLosses.apply(T.to_rows(pred), x_rows, B, Tn, [0, 6, 96, 276, 376], [0.5 - 0.4, 0.4, 0.4, 0.5 - 0.4], 276, 0.01)
+    loss = rec + qo.loss
+    loss.backward()
+    gold = load_gold()
+    assert abs(float(loss) - float(gold["loss"])) < 2e-5 * float(gold["loss"])
+    assert abs(float(qo.loss) - float(gold["e_q_loss"])) < 2e-5 * float(gold["e_q_loss"])
+    assert rel_err(pred.detach().cpu()[:, :, :16], gold["pred"]) < 1e-4
+    named = dict(vq.named_parameters())
+    _check_grads(lambda k: named[k], VQ_TRAIN_GRAD_KEYS, gold, 4, "vqvae_sc")
+    # side effects of the train-mode forward: EMA codebooks (dead codes re-seeded) and BatchNorm running statistics
+    ql = vq.vq_layer
+    for i in range(4):
+        assert rel_err(getattr(ql, f"embeddings_{i}").cpu(), gold[f"embeddings_{i}"]) < 1e-4
+        assert rel_err(ql.ema_cluster_size[i].hidden.cpu(), gold[f"ema_cluster_size_{i}"]) < 1e-5
+        assert rel_err(ql.ema_dw[i].hidden.cpu(), gold[f"ema_dw_{i}"]) < 1e-4
+        assert ql.ema_dw[i].counter == 1
+    assert rel_err(vq.encoder.project.norm.running_mean.cpu(), gold["enc_project_running_mean"]) < 1e-5
+    assert rel_err(vq.decoder._up_4.norm.running_var.cpu(), gold["dec_up4_running_var"]) < 1e-4
+    # eval() sees the updated codebooks and statistics (the packed inference model was dropped)
+    vq.eval()
+    _, qo_e, _ = vq.encode(x[:2])
+    assert qo_e.loss.dtype == torch.int64 and tuple(qo_e.loss.shape) == (2, Tn // 8, 4)
+    cb0 = getattr(ql, "embeddings_0")
+    assert torch.equal(ql.quantize(qo_e.loss[:, :, 0], 0), cb0[qo_e.loss[:, :, 0]])
+
+
+def test_product_quantization_train_forward_alone():
+    """ProductQuantization.forward in train mode on its own (vqvae_modules.py:495-544): STE gradient = identity +
+    commitment term, codes unchanged by the call order."""
+    from oracle import probtalk_oracle_train as OT
+    from probtalk_amd.nets.modules import ProductQuantization
+    G, K, D, B, W = 4, 128, 128, 12, 11
+    pq = ProductQuantization(G * D, K, 0.25, 0.99, num_chunks=G).cuda().train()
+    sd = {"vq_layer." + k: v.detach().cpu().clone() for k, v in pq.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    z = (torch.randn(B, G * D, W, generator=g) * 0.1)
+    dq = torch.randn(B, G * D, W, generator=g)
+    zr = z.clone().requires_grad_(True)
+    q_ref, loss_ref, idx_ref, new = OT.pq_train(sd, "vq_layer.", zr, G, counter=1)
+    (q_ref * dq).sum().add(loss_ref * 3.0).backward()
+    zc = z.cuda().requires_grad_(True)
+    out = pq(zc)
+    (out.quantized * dq.cuda()).sum().add(out.loss * 3.0).backward()
+    assert torch.equal(pq.__dict__["_pt_last_indices"].cpu().reshape(-1, G), idx_ref)
+    assert rel_err(out.quantized.detach().cpu(), q_ref.detach()) < 1e-6
+    assert abs(float(out.loss) - float(loss_ref)) < 1e-5 * float(loss_ref)
+    assert rel_err(zc.grad.cpu(), zr.grad) < 1e-5
+    for i in range(G):
+        assert rel_err(getattr(pq, f"embeddings_{i}").cpu(), new[f"vq_layer.embeddings_{i}"]) < 1e-5
+
+
+def test_legacy_vqvae_train_forward_backward_matches_reference_fixture():
+    from probtalk_amd.nets.modules import VQVAE
+    from tests.test_oracle_legacy_vq_train_golden import legacy_vq_train_case, load_gold
+    m = VQVAE(270, 64, 128, 1024, 2, 512)
+    m.load_state_dict(ref_state_dict("g"))
+    m.cuda().train()
+    x = legacy_vq_train_case().cuda()
+    B, _, Tn = x.shape
+    e_q_loss, recon = m(x)                                          # smplx_body_vq.py:139 -> (e_q_loss, gt_recon)
+    assert tuple(recon.shape) == (B, 270, Tn)
+    ones = torch.ones(B * Tn, device="cuda")
+    rec, sums = T.MaskedL1Losses.apply(T.to_rows(recon), T.ncl_to_rows(x), ones, float(B * Tn), B, Tn, [0, 270], [1.0], 270)
+    loss = rec + e_q_loss
+    loss.backward()
+    gold = load_gold()
+    assert abs(float(loss) - float(gold["loss"])) < 2e-5 * float(gold["loss"])
+    assert rel_err(recon.detach().cpu()[:, :16], gold["pred"]) < 1e-4
+    named = dict(m.named_parameters())
+    _check_grads(lambda k: named[k], LEGACY_VQ_TRAIN_GRAD_KEYS, gold, 4, "legacy vqvae")
+    assert rel_err(m.vq_layer.ema_cluster_size.hidden.cpu(), gold["ema_cluster_size"]) < 1e-5
+    assert rel_err(m.vq_layer.ema_dw.hidden.cpu(), gold["ema_dw"]) < 1e-4
+    assert rel_err(m.encoder.project.norm.running_mean.cpu(), gold["enc_project_running_mean"]) < 1e-5
+
+
+def test_rtransformer_train_forward_backward_matches_reference_fixture():
+    from probtalk_amd.nets.transformer_modules import RTransformer
+    from tests.test_oracle_refiner_train_golden import load_gold
+    rt = RTransformer(376, 768, 512, 6, use_label=True, motion_context=True)
+    rt.load_state_dict(ref_state_dict("HFTransformer"))
+    rt.cuda().train()
+    _no_dropout(rt)
+    aud, inp, gt, mask, label = refiner_train_case()
+    B, _, Tn = aud.shape
+    pred = rt(inp.cuda(), aud.cuda(), mask.cuda(), label.cuda())    # refiner.py:296
+    assert tuple(pred.shape) == (B, 376, Tn) and pred.requires_grad
+    nmask = (1.0 - mask).reshape(-1).contiguous().cuda()
+    loss, sums = T.MaskedL1Losses.apply(T.to_rows(pred), T.ncl_to_rows(gt.cuda()), nmask, float(nmask.sum()), B, Tn,
+                                        [0, 6, 96, 276, 376], [0.25] * 4, 276)
+    loss.backward()
+    gold = load_gold()
+    assert abs(float(loss) - float(gold["loss"])) < 1e-5 * float(gold["loss"])
+    named = dict(rt.named_parameters())
+    _check_grads(lambda k: named[k], REFINER_TRAIN_GRAD_KEYS, gold, 8, "refiner")
+
+
+def test_train_mode_dropout_is_seeded_and_replayed():
+    """Dropout on (p = 0.1 as built): two calls from the same seed position give identical outputs and gradients, a
+    different position gives different ones; eval() output has no dropout."""
+    from probtalk_amd.nets.modules import ConditionEncoder
+    ae = ConditionEncoder(768, 256, 2, 256)
+    ae.load_state_dict(ref_state_dict("AudEnc"))
+    ae.cuda().train()
+    x = torch.randn(3, 768, 64, device="cuda")
+    runs = []
+    for pos in (0, 0, 7):
+        ae.__dict__["_pt_seeds"] = T._Seeds(11)
+        ae.__dict__["_pt_seeds"].n = pos
+        ae.zero_grad()
+        y = ae(x)
+        y.square().mean().backward()
+        runs.append((y.detach().clone(), ae.feature_map[0].weight.grad.clone()))
+    assert torch.equal(runs[0][0], runs[1][0])                       # same masks
+    assert rel_err(runs[0][1].cpu(), runs[1][1].cpu()) < 1e-5        # weight gradients are summed with atomics: order varies
+    assert not torch.equal(runs[0][0], runs[2][0])
+    assert bool(torch.isfinite(runs[2][1]).all())
+    seeds = ae.__dict__["_pt_seeds"]
+    s2 = T._Seeds(0)
+    s2.load_state_dict(seeds.state_dict())              # what the wrappers checkpoint as 'dropout_seeds'
+    assert s2.next() == seeds.next()

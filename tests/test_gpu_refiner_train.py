@@ -147,4 +147,4 @@ def test_refiner_wrapper_first_step_and_training():
         assert math.isfinite(ld["loss"]) and math.isfinite(ld["grad_HF"])
         losses.append(ld["loss"])
     assert min(losses[-2:]) < losses[0], losses
-    assert set(ref.state_dict()) == {"HFTransformer", "AudEnc", "generator_optim"}
+    assert set(ref.state_dict()) == {"HFTransformer", "AudEnc", "generator_optim", "dropout_seeds"}

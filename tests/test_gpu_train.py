@@ -483,7 +483,8 @@ def test_train_wrapper_loss_decreases_with_dropout():
     assert min(losses[-3:]) < losses[0] - 0.1, losses
     assert pred.global_step == 12
     sd = pred.state_dict()
-    assert set(sd) == {"AudEnc", "Predictor", "TextEnc", "generator_optim"}
+    assert set(sd) == {"AudEnc", "Predictor", "TextEnc", "generator_optim", "dropout_seeds"}
+    assert sd["dropout_seeds"]["n"] > 0
     # inference still works on the updated weights
     out, _ = pred.infer_on_batch(aud=bat["aud_feat"][:1].cuda(), text=None, id=torch.tensor([0]).cuda(), B=1,
                                  gt_poses=torch.zeros(1, 376, 180, device="cuda"), mask=torch.zeros(1, 1, 180, device="cuda"))

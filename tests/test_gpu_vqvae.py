@@ -181,7 +181,13 @@ def test_vqvae_errors():
     with pytest.raises(RuntimeError):
         vq.encode(torch.zeros(1, 376, 4, device="cuda"))       # shorter than the x8 downsampling
     with pytest.raises(NotImplementedError):
-        vq.train()(torch.zeros(1, 376, 88, device="cuda"))
+        vq.encode(torch.zeros(1, 376, 88, device="cuda"), r=0.1)          # token replacement: off in every config
+    # train mode is a real path (tests/test_gpu_module_train.py), not a raise
+    vq.cuda().train()
+    out = vq(torch.randn(12, 376, 88, device="cuda"))           # 132 latent rows: the EMA re-seeding needs >= 128 (codes)
+    assert out.requires_grad and tuple(out.shape) == (12, 376, 88)
+    with pytest.raises(RuntimeError):                             # parameters left on the CPU: refused, not dereferenced
+        _vq().train()(torch.randn(12, 376, 88, device="cuda"))
 
 
 def test_legacy_vq():
