@@ -38,7 +38,8 @@ pt_model* pt_model_create(const char* kind, const int* cfg, int ncfg);
  * dtype: 0 = float32, 1 = float64 (positional-encoding tables). */
 int pt_model_set_tensor(pt_model* m, const char* name, const void* host_data, const int64_t* shape, int ndim, int dtype);
 /* Arithmetic: 0 = fp32 (default; parity path, 1e-4), 1 = bf16 MFMA operands with fp32 accumulation (BASELINE configs[2];
- * tolerance 1e-2): predictor / refiner transformers (fp32 residual stream and LayerNorm), the motion-context and audio
+ * tolerance 1e-2 as l2-relative error): predictor / refiner transformers (LayerNorm statistics from the fp32
+ * accumulators; the residual stream itself is bf16 unless option "resid_bf16" is 0), the motion-context and audio
  * condition encoders, and the PQ-VAE DECODER.  PQ-VAE encode + nearest-code search always run in fp32 (bit-exact
  * indices).  Not available for "vqvae_legacy".  Call before pt_model_finalize. */
 int pt_model_set_precision(pt_model* m, int precision);
@@ -273,6 +274,15 @@ int pt_train_masked_l1_losses(const float* pred, int ldp, const float* gt, int l
 int pt_train_sqdiff(const float* a, const float* b, size_t n, float* out, void* stream);
 int pt_train_commit_bwd(const float* dq, const float* z, const float* q, const float* g, float coef, size_t n, float* dz,
                         void* stream);
+/* Pose post-process of a generated batch, one kernel (scripts/demo.py:183-205): pred (B,376,T) network output ->
+ * out (B*T rows, ld_out floats): optional denormalisation x*std + mean with the statistics gathered per channel as
+ * nets/utils.py:16-43 does for shape 'fbhe' (mean / std: n_stats floats, the two halves of data_utils/norm_stats.npy
+ * (2,1,1,430); c_index: the 270 int32 of data_utils/lower_body.py:54-63; NULL mean = normalisation off), 6-D ->
+ * rotation matrix -> axis-angle for the 46 joints (data_utils/rotation_conversion.py:512-533,97-119,481-509), the 100
+ * expression coefficients appended, and part2full's 27 fixed lower-body scalars inserted (data_utils/lower_body.py:66-83;
+ * lower_pose NULL = skip, rows of 238 instead of 265). */
+int pt_postprocess_poses(const float* pred, int B, int T, const float* mean, const float* std_, const int* c_index,
+                         int n_stats, const float* lower_pose, float* out, int ld_out, void* stream);
 /* The library's only run-time switches; it reads no environment variables.  Set them before the calls they affect, from
  * one thread (they are plain process-wide ints).  No counterpart in the reference: they select between kernels that
  * compute the same thing (A/B measurements and tests), except resid_bf16, which moves the bf16 mode's rounding points.

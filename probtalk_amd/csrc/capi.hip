@@ -374,6 +374,10 @@ int pt_gemm_bf16_addln(const void* A, int lda, const void* W, const float* bias,
   b.Cb = (unsigned short*)x_bf16; b.ldcb = 512; b.gamma = gamma; b.beta = beta; b.X = x;
   return launch_gemm_big(b, (hipStream_t)stream);
 }
+int pt_postprocess_poses(const float* pred, int B, int T, const float* mean, const float* std_, const int* c_index,
+                         int n_stats, const float* lower_pose, float* out, int ld_out, void* stream) {
+  return launch_postprocess(pred, B, T, mean, std_, c_index, n_stats, lower_pose, out, ld_out, (hipStream_t)stream);
+}
 int pt_permute_k32(const void* W, void* out, int N, int K, void* stream) {
   return launch_permute_k32((const unsigned short*)W, (unsigned short*)out, N, K, (hipStream_t)stream);
 }

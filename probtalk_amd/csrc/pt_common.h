@@ -153,6 +153,10 @@ int launch_ncl_to_cl_b(const float* in, unsigned short* out, int B, int C, int L
                        hipStream_t s);
 int launch_cl_to_ncl(const float* in, int ldi, int col_off, float* out, int B, int C, int L, hipStream_t s);
 
+// pose post-process (postprocess.hip)
+int launch_postprocess(const float* pred, int B, int T, const float* mean, const float* stdv, const int* cidx, int n_stats,
+                       const float* lower, float* out, int ld, hipStream_t s);
+
 // product quantizer
 int launch_pq_search(const float* z_cl, int ldz, const float* codebooks, int rows, int G, int D, int K,
                      int64_t* idx, float* q_cl, int ldq, hipStream_t s);
