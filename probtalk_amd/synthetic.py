@@ -26,6 +26,52 @@ def write_vq_checkpoint(path, seed=0):
     return path
 
 
+def _torch_adamw_state(params, lr, betas, steps=0, seed=0):
+    """A torch.optim.AdamW.state_dict()-shaped entry ('generator_optim' in the reference's checkpoints, predictor.py:136):
+    per-parameter step / exp_avg / exp_avg_sq keyed by position, one param_group."""
+    g = torch.Generator().manual_seed(seed + 77)
+    state = {}
+    if steps > 0:
+        for i, p in enumerate(params):
+            state[i] = {"step": torch.tensor(float(steps)), "exp_avg": 1e-3 * torch.randn(p.shape, generator=g),
+                        "exp_avg_sq": 1e-6 * torch.rand(p.shape, generator=g)}
+    return {"state": state, "param_groups": [{"lr": lr, "betas": tuple(betas), "eps": 1e-8, "weight_decay": 1e-2,
+                                              "amsgrad": False, "params": list(range(len(params)))}]}
+
+
+def write_reference_checkpoints(outdir, seed=0, optim_steps=3):
+    """Files laid out as the reference's trainer writes them (trainer/Trainer.py:201-216: {'generator':
+    wrapper.state_dict(), 'epoch', 'global_steps'} in ckpt-<epoch>.pth) for the three wrappers of the path, on generator
+    weights: the per-module dicts carry the `module.` prefix nn.DataParallel gives them (predictor.py:100-105,128-143;
+    refiner.py's likewise), the positional tables are float64 (PTransformer.py:227-245), and 'generator_optim' is a
+    torch.optim.AdamW state_dict.  Returns {'vq': path, 'predictor': path, 'refiner': path}."""
+    from .nets.modules import VQVAE_SC, ConditionEncoder
+    from .nets.transformer_modules import PredictorNet, RTransformer
+    os.makedirs(outdir, exist_ok=True)
+    par = lambda sd: {"module." + k: v.clone() for k, v in sd.items()}
+    vq = fill_module(VQVAE_SC(376, 512, 128, 1024, 2, 512, q_type="pro", groups=4), seed, "VQ.")
+    ae = fill_module(ConditionEncoder(768, 256, 2, 256), seed, "AudEnc.")
+    te = ConditionEncoder(768, 256, 2, 256)
+    pn = fill_module(PredictorNet(False, 376, 128, 512, 10, 6, 4, groups=4, identity=True, maskgit=True, maskgit_T=8,
+                                  transformer=True, text=None, audio="wav2vec", motion_context=True), seed, "Predictor.")
+    rt = fill_module(RTransformer(376, 768, 512, 6, use_label=True, motion_context=True), seed, "HFTransformer.")
+    assert pn.state_dict()["decoder.PE.position_encoding.weight"].dtype == torch.float64
+    paths = {k: os.path.join(outdir, k, "ckpt-99.pth") for k in ("vq", "predictor", "refiner")}
+    for p in paths.values():
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+    torch.save({"generator": {"VQ": vq.state_dict(),
+                              "generator_optim": _torch_adamw_state(list(vq.parameters()), 1e-4, (0.9, 0.999), 0, seed)},
+                "epoch": 99, "global_steps": 12345}, paths["vq"])
+    p_params = list(ae.parameters()) + list(pn.parameters()) + list(te.parameters())
+    torch.save({"generator": {"AudEnc": par(ae.state_dict()), "Predictor": par(pn.state_dict()), "TextEnc": par(te.state_dict()),
+                              "generator_optim": _torch_adamw_state(p_params, 1e-4, (0.9, 0.99), optim_steps, seed)},
+                "epoch": 99, "global_steps": 23456}, paths["predictor"])
+    torch.save({"generator": {"HFTransformer": par(rt.state_dict()), "AudEnc": {},
+                              "generator_optim": _torch_adamw_state(list(rt.parameters()), 1e-4, (0.9, 0.99), optim_steps, seed)},
+                "epoch": 99, "global_steps": 34567}, paths["refiner"])
+    return paths
+
+
 def build_pipeline(seed=0, tmpdir=None):
     """(predictor wrapper, refiner wrapper) = the two body models All_In_One_Model chains (ai1.py:36-42)."""
     from . import nets

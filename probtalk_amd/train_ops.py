@@ -569,6 +569,11 @@ class AdamW:
                 st = self.state.get(p)
                 if st is None:
                     st = self.state[p] = {"step": 0, "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
+                if not p.is_cuda:
+                    raise RuntimeError("AdamW.step: parameters must be on the GPU")
+                for k in ("exp_avg", "exp_avg_sq"):        # state restored before the module moved to the GPU
+                    if st[k].device != p.device:
+                        st[k] = st[k].to(p.device)
                 st["step"] += 1
                 c = None if coefs is None else coefs.get(p)
                 gr = p.grad.contiguous()
