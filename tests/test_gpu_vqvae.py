@@ -133,7 +133,8 @@ def test_pq_ties_pick_lowest_index():
     assert torch.all(qo.loss.cpu() == 5)
 
 
-@pytest.mark.parametrize("B,T,name", [(2, 88, "vq_b2_t88.npz"), (8, 88, None), (3, 300, None), (1, 8, None)])
+# (256, 88) is BASELINE configs[1] at its full size: 22,528 frames, 2,816 latent rows x 4 sub-codebooks
+@pytest.mark.parametrize("B,T,name", [(2, 88, "vq_b2_t88.npz"), (8, 88, None), (3, 300, None), (1, 8, None), (256, 88, None)])
 def test_vqvae_encode_decode(B, T, name):
     vq = _vq()
     sd = ref_state_dict("VQ")
