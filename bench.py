@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-arithmetic leg of the default bf16 run")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="library switch for A/B runs (pt_set_option: resid_bf16, fused_tail, small_rows, row_tile, ...)")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and (a.gpus or 1) > 1:
@@ -215,6 +217,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev, timeout=tmo)      # RCCL over xGMI
         else:
             dist.init_process_group(backend, timeout=tmo)
+    for kv in a.option:
+        from probtalk_amd import _lib
+        name, _, val = kv.partition("=")
+        _lib.check(_lib.lib().pt_set_option(name.encode(), int(val)))
     if a.workload == "train":
         train_bench(a, rank, world, dev)
         if world > 1:

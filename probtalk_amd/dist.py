@@ -99,6 +99,10 @@ class OutputGatherer:
         return self.bufs[(self.i - 1) % 2]
 
 
+# tools/micro/dist_train_debug.py sets this to hand gloo the device tensors themselves (the configuration that hung)
+GLOO_DEVICE_TENSORS = False
+
+
 class GradientReducer:
     """Data-parallel training: averages the gradients of `params` over all ranks in flat buckets.
 
@@ -152,7 +156,7 @@ class GradientReducer:
         torch.cat([p.grad.reshape(-1) for p in live], out=flat)
         # gloo (CPU rehearsals, or several ranks on one GPU in tests) gets a host copy: its own staging of device tensors
         # deadlocked with several collectives in flight on this ROCm build; RCCL reduces the device buffer in place
-        msg = flat.cpu() if flat.is_cuda and dist.get_backend() == "gloo" else flat
+        msg = flat.cpu() if flat.is_cuda and dist.get_backend() == "gloo" and not GLOO_DEVICE_TENSORS else flat
         self._pending[i] = (dist.all_reduce(msg, op=dist.ReduceOp.SUM, async_op=True), flat, live, msg)
 
     def _on_grad(self, p):

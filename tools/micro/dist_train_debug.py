@@ -4,7 +4,7 @@ import torch, torch.distributed as dist, torch.multiprocessing as mp
 
 
 def w(rank, port):
-    faulthandler.dump_traceback_later(140, exit=True)
+    faulthandler.dump_traceback_later(60, exit=True)
     import time
     t00 = time.time()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -13,6 +13,7 @@ def w(rank, port):
     from probtalk_amd import synthetic, dist as D
     from probtalk_amd.weights import make_input
     import threading
+    D.GLOO_DEVICE_TENSORS = len(sys.argv) > 2 and sys.argv[2] == 'device'
     orig = D.GradientReducer._launch
     def dbg(self, i):
         live = [p for p in self.buckets[i] if p.grad is not None]
