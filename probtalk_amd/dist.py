@@ -154,8 +154,12 @@ class GradientReducer:
             return
         flat = self._flat_for(i, sum(p.numel() for p in live), live[0].grad)
         torch.cat([p.grad.reshape(-1) for p in live], out=flat)
-        # gloo (CPU rehearsals, or several ranks on one GPU in tests) gets a host copy: its own staging of device tensors
-        # deadlocked with several collectives in flight on this ROCm build; RCCL reduces the device buffer in place
+        # gloo (CPU rehearsals, or several ranks on one GPU in tests) gets a host copy.  Handed the device buffers, the
+        # predictor's six buckets (7.1-9.9 M floats each; one launched from the autograd thread, five from reduce(), same
+        # order on both ranks) are all in flight as async all_reduce and the first work.wait() never returns on either
+        # rank (profiles/r2/gloo_device_tensor_hang.txt; three 64 K-float all_reduce launched the same way complete,
+        # profiles/r2/gloo_cuda_probe_small.txt).  RCCL reduces the device buffer in place; a stuck collective there ends
+        # the job through init_process_group's timeout (bench.py)
         msg = flat.cpu() if flat.is_cuda and dist.get_backend() == "gloo" and not GLOO_DEVICE_TENSORS else flat
         self._pending[i] = (dist.all_reduce(msg, op=dist.ReduceOp.SUM, async_op=True), flat, live, msg)
 
