@@ -132,6 +132,12 @@ int pt_interp_blend(const float* pred, int B, int C, int T_in, int T_out, const 
  * [k][Npad][Kpad], out [B*Lout, ldc].  kind: 0=k1 1=k3 2=k7 3=k4s2 4=convT k4s2. act: 0 none 1 leaky(slope) 2 gated. */
 int pt_conv1d_cl(const float* A, int lda, const float* Wpacked, const float* bias, int N, int Npad, int K, int kind,
                  int B, int Lin, float* C, int ldc, int act, float slope, const float* Res, int ldr, void* stream);
+/* The same conv on bf16 operands (bf16 mode of the conv stacks): A [B*Lin, lda] bf16 channels-last, Wpacked
+ * [taps][Npad][K] bf16 (K % 64 == 0), fp32 accumulation; output fp32 rows (C) and/or bf16 rows (Cb); optional bf16
+ * residual indexed by output row.  Large shapes run on the phase-pipelined LDS-DMA tap-GEMM (option "conv8"). */
+int pt_conv1d_cl_bf16(const void* A, int lda, const void* Wpacked, const float* bias, int N, int Npad, int K, int kind, int B,
+                      int Lin, float* C, int ldc, void* Cb, int ldcb, int act, float slope, const void* ResB, int ldr,
+                      void* stream);
 int pt_ncl_to_cl(const float* in, float* out, int B, int C, int L, int ldo, void* stream);
 int pt_cl_to_ncl(const float* in, int ldi, float* out, int B, int C, int L, void* stream);
 /* nearest-code search on channels-last rows: z [rows, ldz], codebooks [G][K][D] -> idx (rows,G), q [rows, ldq]. */
@@ -292,6 +298,7 @@ int pt_postprocess_poses(const float* pred, int B, int T, const float* mean, con
  *   "small_rows"         rows up to which wide Linears (N != 512) take the 4-wave kernel (default 2048)
  *   "row_tile"           0 (default) the N = 512 row kernel picks its tile height; 2 | 4 | 8 | 10 forces 16 x that many rows
  *   "attn_train_rowwise" 1 = training attention on the row-wise kernels whatever the shape (default 0)
+ *   "conv8"              1 (default) conv stacks of the bf16 mode on the phase-pipelined LDS-DMA tap-GEMM where it applies
  * Unknown names and out-of-range values are errors (non-zero return, pt_last_error). */
 int pt_set_option(const char* name, int value);
 int pt_get_option(const char* name, int* value);

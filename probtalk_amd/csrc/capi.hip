@@ -73,8 +73,8 @@ int scratch_for_current_device(void** out) {
 }
 
 // ---- run-time options (pt_common.h: Option).  Plain ints: set them before the calls they affect, from one thread.
-int g_opt[pt::OPT_COUNT] = {1, -1, 2048, 0, 0};
-const char* const g_opt_name[pt::OPT_COUNT] = {"resid_bf16", "fused_tail", "small_rows", "row_tile", "attn_train_rowwise"};
+int g_opt[pt::OPT_COUNT] = {1, -1, 2048, 0, 0, 1};
+const char* const g_opt_name[pt::OPT_COUNT] = {"resid_bf16", "fused_tail", "small_rows", "row_tile", "attn_train_rowwise", "conv8"};
 int find_option(const char* name) {
   if (name)
     for (int i = 0; i < pt::OPT_COUNT; ++i)
@@ -94,7 +94,7 @@ int pt_version(void) { return 100; }
 
 int pt_set_option(const char* name, int value) {
   const int i = find_option(name);
-  PT_CHECK(i >= 0, "pt_set_option: unknown option '%s' (resid_bf16, fused_tail, small_rows, row_tile, attn_train_rowwise)", name ? name : "(null)");
+  PT_CHECK(i >= 0, "pt_set_option: unknown option '%s' (resid_bf16, fused_tail, small_rows, row_tile, attn_train_rowwise, conv8)", name ? name : "(null)");
   PT_CHECK(i != OPT_ROW_TILE || value == 0 || value == 2 || value == 4 || value == 8 || value == 10, "pt_set_option: row_tile = 0, 2, 4, 8 or 10");
   PT_CHECK(i != OPT_FUSED_TAIL || (value >= -1 && value <= 1), "pt_set_option: fused_tail = -1 (auto), 0 or 1");
   PT_CHECK(i != OPT_SMALL_ROWS || value >= 0, "pt_set_option: small_rows >= 0");
@@ -309,6 +309,21 @@ int pt_conv1d_cl(const float* A, int lda, const float* Wpacked, const float* bia
   static const int slabs[] = {1, 3, 7, 4, 4};
   c.slabs = slabs[kind];
   return run_conv(c, (ConvKind)kind, A, lda, B, Lin, C, ldc, act, slope, Res, ldr, (hipStream_t)stream);
+}
+int pt_conv1d_cl_bf16(const void* A, int lda, const void* Wpacked, const float* bias, int N, int Npad, int K, int kind, int B,
+                      int Lin, float* C, int ldc, void* Cb, int ldcb, int act, float slope, const void* ResB, int ldr,
+                      void* stream) {
+  PT_CHECK(A && Wpacked && (C || Cb), "pt_conv1d_cl_bf16: null argument");
+  PT_CHECK(kind >= 0 && kind <= 4, "pt_conv1d_cl_bf16: kind %d out of range", kind);
+  if (conv8_prepare()) return 1;
+  DevConv c;
+  c.wb = (unsigned short*)const_cast<void*>(Wpacked);
+  c.b = const_cast<float*>(bias);
+  c.N = N; c.Npad = Npad; c.K = K; c.Kb = K; c.Cin = K;
+  static const int slabs[] = {1, 3, 7, 4, 4};
+  c.slabs = slabs[kind];
+  return run_conv_b(c, (ConvKind)kind, (const bf16_t*)A, lda, B, Lin, C, ldc, (bf16_t*)Cb, ldcb, act, slope, (const bf16_t*)ResB,
+                    ldr, (hipStream_t)stream, nullptr, -1);
 }
 int pt_ncl_to_cl(const float* in, float* out, int B, int C, int L, int ldo, void* stream) {
   PT_CHECK(in && out, "pt_ncl_to_cl: null argument");

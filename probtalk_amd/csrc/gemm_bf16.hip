@@ -216,6 +216,7 @@ int launch_gemm_bf16(const GemmArgsB& a, hipStream_t s) {
     PT_CHECK(a.N % 64 == 0, "gemm_bf16: gated N=%d must be a multiple of 64", a.N);
     PT_CHECK(!a.pe && !a.Res && !a.ResB, "gemm_bf16: gated epilogue takes no pe/residual");
   }
+  if (option(OPT_CONV8) && conv8_takes(a)) return launch_conv8(a, s);
   auto tiles = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   if (tiles(128, 128) >= 512) return launch_cfg_b<2, 2>(a, s);
   if (tiles(64, 128) >= 384 || a.act == ACT_GATED) return launch_cfg_b<1, 2>(a, s);

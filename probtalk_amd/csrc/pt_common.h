@@ -94,6 +94,10 @@ struct GemmArgsB {
   double flops;
 };
 int launch_gemm_bf16(const GemmArgsB& a, hipStream_t s);
+// phase-pipelined 256 x 256 LDS-DMA variant for the conv stacks (gemm_bf16_conv.hip); launch_gemm_bf16 dispatches to it
+int conv8_prepare();                        // allocates the per-device zero block (model finalize time)
+bool conv8_takes(const GemmArgsB& a);
+int launch_conv8(const GemmArgsB& a, hipStream_t s);
 
 // Large-tile bf16 Linear (gemm_bf16_big.hip): 256x256 tiles, or 128x512 tiles that own whole d_model=512
 // rows and can fuse the LayerNorm that follows the Linear in the decoder layer.
@@ -143,6 +147,7 @@ enum Option {
   OPT_SMALL_ROWS,          // rows up to which wide Linears (N != 512) take the 4-wave kernel (default 2048)
   OPT_ROW_TILE,            // 0 (default): row kernel picks its tile height; 2 | 4 | 8 | 10 forces 16 x that many rows
   OPT_ATTN_TRAIN_ROWWISE,  // 1: training attention on the row-wise kernels whatever the shape (default 0)
+  OPT_CONV8,               // 1 (default): conv stacks of the bf16 mode on the phase-pipelined LDS-DMA kernel where it applies
   OPT_COUNT
 };
 int option(Option o);

@@ -193,6 +193,7 @@ int finalize_model(Model& m) {
   else if (m.kind == "cond_encoder") rc = finalize_cond_encoder(m);
   else rc = finalize_transformer_models(m);
   if (rc) return rc;
+  if (conv8_prepare()) return 1;
   PT_HIP(hipDeviceSynchronize());
   m.finalized = true;
   m.sd.clear();  // host copies are no longer needed
