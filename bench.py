@@ -139,11 +139,11 @@ def gemm_roofline(pred, ref, inputs, dtype, ms_per_step, B, T):
     ms, fl, ln = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int * 8)()
     _lib.check(L.pt_prof_read(ms, fl, ln))
     _lib.check(L.pt_prof_enable(0))
-    names = ("f32 128x128", "f32 64x128", "f32 64x64", "bf16 128x128", "bf16 64x128", "bf16 64x64",
-             "bf16 256x256 8-phase lds-dma (gemm8_kernel)", "bf16 160x512 row-complete +LN epilogues (gemm_row_kernel)")
+    names = ("f32 128x128", "f32 64x128", "f32 64x64", "bf16 conv stacks: 256x256 lds-dma tap-GEMM (conv8_kernel) + 4-wave 128x128", "bf16 64x128", "bf16 64x64",
+             "bf16 256x256 8-phase lds-dma (gemm8_kernel)", "bf16 N=512 row-complete +LN epilogues (gemm_row_kernel, sublayer_kernel)")
     dom = range(3, 8) if dtype == "bf16" else range(0, 3)     # the dominant kernel family of this mode
     peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-    kname = "pt::gemm_row_kernel + pt::gemm8_kernel + pt::gemm_bf16_kernel (bf16 MFMA GEMMs of the transformers and conv stacks)" \
+    kname = "pt::gemm_row_kernel + pt::gemm8_kernel + pt::conv8_kernel + pt::gemm_bf16_kernel (bf16 MFMA GEMMs of the transformers and conv stacks)" \
         if dtype == "bf16" else "pt::gemm_f32_kernel (tap-GEMM, fp32 MFMA 32x32x2)"
     tot_ms, tot_fl, tot_n = sum(ms[i] for i in dom), sum(fl[i] for i in dom), sum(ln[i] for i in dom)
     ach = tot_fl / (tot_ms * 1e-3) / 1e12
@@ -290,7 +290,7 @@ def main():
         if a.dtype == "bf16" and pmc_path:
             with open(pmc_path) as f:
                 pk = json.load(f)["kernels"]
-            fam = {k: v for k, v in pk.items() if any(t in k for t in ("gemm_row_kernel", "gemm8_kernel", "gemm_big_kernel", "gemm_bf16_kernel", "sublayer_kernel", "conv_bf16_kernel"))}
+            fam = {k: v for k, v in pk.items() if any(t in k for t in ("gemm_row_kernel", "gemm8_kernel", "gemm_big_kernel", "gemm_bf16_kernel", "sublayer_kernel", "conv8_kernel"))}
             n = sum(v["launches"] for v in fam.values())
             if n:
                 res["roofline"]["traffic"] = sum(v["launches"] * v["hbm_bytes_per_launch"] for v in fam.values()) / n
