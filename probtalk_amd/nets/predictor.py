@@ -61,9 +61,9 @@ class TrainWrapper(TrainWrapperBaseClass):
         for i in range(self.random_mask.shape[0]):
             self.random_mask[i, 0, i:(i + 30)] = 1
         self.train_dropout = 0.1                                        # nn.TransformerDecoderLayer / ConditionEncoder dp
-        # dropout seed stream of the training step.  Each rank draws its own masks; the position in the stream is checkpointed.
-        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
-        self._seeds = train_ops._Seeds(rank)
+        # dropout seed stream of the training step: each rank draws its own masks (train_ops._Seeds folds the rank in), the
+        # position in the stream is checkpointed ('dropout_seeds')
+        self._seeds = train_ops._Seeds(0)
         super().__init__(args, config)
 
     def to_parallel(self):

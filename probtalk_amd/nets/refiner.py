@@ -57,8 +57,7 @@ class TrainWrapper(TrainWrapperBaseClass):
         for i in range(self.random_mask.shape[0]):
             self.random_mask[i, 0, i:(i + 30)] = 1
         self.train_dropout = 0.1
-        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
-        self._seeds = train_ops._Seeds(1 + 2 * rank)              # per-rank dropout masks; position checkpointed
+        self._seeds = train_ops._Seeds(1)                         # per-rank dropout masks (rank folded in); position checkpointed
         super().__init__(args, config)
 
     def to_parallel(self):

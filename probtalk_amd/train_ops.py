@@ -353,14 +353,18 @@ class Dropout(torch.autograd.Function):
 
 
 class _Seeds:
-    """Per-step dropout seed stream (host counter; the device never sees torch's RNG)."""
+    """Per-step dropout seed stream (host counter; the device never sees torch's RNG).  The rank of the process is folded
+    into every seed when it is drawn, so data-parallel replicas draw independent masks (as nn.DataParallel's replicas do)
+    whenever the process group was initialised; the position `n` is checkpointed by the wrappers."""
 
     def __init__(self, seed=0):
         self.base, self.n = int(seed) & 0xFFFFFFFF, 0
 
     def next(self):
+        import torch.distributed as dist
         self.n += 1
-        return (self.base << 20) + self.n
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        return (((self.base ^ (rank << 16)) & 0xFFFFFFFF) << 20) + self.n
 
     def state_dict(self):
         return {"base": self.base, "n": self.n}
