@@ -49,7 +49,8 @@ struct DecLayer {
 struct GatedW { DevConv vert, res, skip; ConvKind kind; int dim, in_dim; bool strided; };
 
 struct Predictor {
-  int mot_dim, num_codes, groups, n_classes, n_layers, audio_dim;
+  int mot_dim, num_codes, groups, n_classes, n_layers, audio_dim;   // audio_dim: audio (+ text) feature channels
+  int cond_w = 768;       // condition width = motion 512 + audio_dim (768; 1024 with text features)
   DevConv motion_emb, condi_emb, out0, out2;
   GatedW enc[10];
   float* tok_emb = nullptr;
@@ -213,6 +214,8 @@ static int finalize_predictor(Model& m) {
   if (pack_conv_public(m, P->condi_emb, "decoder.condi_emb", "", "", false, false)) return 1;
   PT_CHECK(P->condi_emb.Cin == d + P->audio_dim, "condi_emb expects %d channels, motion %d + audio %d given",
            P->condi_emb.Cin, d, P->audio_dim);
+  P->cond_w = d + P->audio_dim;
+  PT_CHECK(P->cond_w % 64 == 0 && P->audio_dim > 0, "predictor: condition width %d must be a multiple of 64", P->cond_w);
   if (pack_conv_public(m, P->out0, "decoder.output_conv.0", "", "", false, false)) return 1;
   if (pack_conv_public(m, P->out2, "decoder.output_conv.2", "", "", false, false)) return 1;
   PT_CHECK(P->out2.N == P->num_codes, "output head has %d classes, %d codes expected", P->out2.N, P->num_codes);
@@ -419,12 +422,12 @@ size_t predictor_workspace_bytes(const Model& m, int B, int T) {
   const size_t R = (size_t)B * Tq * P.groups;
   const size_t cond_phase = (size_t)B * T * (ld_of(P.mot_dim + 1) + 4 * 128);
   // fp32 sizing covers the bf16 mode too (its buffers are half as wide, plus the small V^T scratch)
-  const size_t trans = (size_t)B * Tq * (2 * 768 + DM + (size_t)P.n_layers * 3 * DM) +
+  const size_t trans = (size_t)B * Tq * (2 * (size_t)P.cond_w + DM + (size_t)P.n_layers * 3 * DM) +
                        R * (DM * 7 + FF + P.num_codes + 1) + vt_elems(B, Tq * P.groups);
-  return (std::max(cond_phase + (size_t)B * Tq * 768, trans) * sizeof(float) + 96 * 256 + 255) & ~(size_t)255;
+  return (std::max(cond_phase + (size_t)B * Tq * P.cond_w, trans) * sizeof(float) + 96 * 256 + 255) & ~(size_t)255;
 }
 
-// motion-context encoder; writes channels-last condition rows [B*Tq, 768] (motion | audio)
+// motion-context encoder; writes channels-last condition rows [B*Tq, cond_w] (motion | audio [| text])
 static int predictor_condition_cl(const Predictor& P, const float* masked_motion, const float* mask, const float* audio,
                                   int B, int T, float* cond_cl, Arena& ar, hipStream_t s) {
   const int ldm = ld_of(P.mot_dim + 1);
@@ -450,13 +453,13 @@ static int predictor_condition_cl(const Predictor& P, const float* masked_motion
     }
     const bool last = i == 9;
     float* dst = last ? cond_cl : o;
-    if (run_conv(gw.res, CONV_K1, g, ldd, B, Lo, dst, last ? 768 : ldd, ACT_NONE, 1.f, res, ldr, s, nullptr,
+    if (run_conv(gw.res, CONV_K1, g, ldd, B, Lo, dst, last ? P.cond_w : ldd, ACT_NONE, 1.f, res, ldr, s, nullptr,
                  last ? gw.dim : -1)) return 1;
     if (!last) { float* t = h; h = o; o = t; }
     L = Lo;
   }
-  // audio features (B, audio_dim, Tq) NCL -> columns [512, 768)
-  return launch_ncl_to_cl(audio, cond_cl, B, P.audio_dim, L, 768, P.enc[9].dim, P.enc[9].dim + P.audio_dim, s);
+  // audio (+ text) features (B, audio_dim, Tq) NCL -> columns [512, cond_w)
+  return launch_ncl_to_cl(audio, cond_cl, B, P.audio_dim, L, P.cond_w, P.enc[9].dim, P.enc[9].dim + P.audio_dim, s);
 }
 
 // bf16 mode of the motion-context encoder: bf16 rows between the gated convs, fp32 condition rows at the end
@@ -487,12 +490,12 @@ static int predictor_condition_cl_b(const Predictor& P, const float* masked_moti
       ldr = ldd;
     }
     const bool last = i == 9;
-    if (run_conv_b(gw.res, CONV_K1, g, ldd, B, Lo, last ? cond_cl : nullptr, last ? 768 : 0, last ? nullptr : o, ldd,
+    if (run_conv_b(gw.res, CONV_K1, g, ldd, B, Lo, last ? cond_cl : nullptr, last ? P.cond_w : 0, last ? nullptr : o, ldd,
                    ACT_NONE, 1.f, res, ldr, s, nullptr, gw.dim)) return 1;
     if (!last) { bf16_t* t = h; h = o; o = t; }
     L = Lo;
   }
-  return launch_ncl_to_cl(audio, cond_cl, B, P.audio_dim, L, 768, P.enc[9].dim, P.enc[9].dim + P.audio_dim, s);
+  return launch_ncl_to_cl(audio, cond_cl, B, P.audio_dim, L, P.cond_w, P.enc[9].dim, P.enc[9].dim + P.audio_dim, s);
 }
 
 int predictor_condition(Model& m, const float* masked_motion, const float* mask, const float* audio, int B, int T,
@@ -500,13 +503,12 @@ int predictor_condition(Model& m, const float* masked_motion, const float* mask,
   PT_CHECK(m.finalized && m.pred, "predictor_condition: wrong or unfinalized model");
   PT_CHECK(B > 0 && T >= 8, "predictor_condition: need B>0, T>=8 (B=%d T=%d)", B, T);
   const Predictor& P = *m.pred;
-  PT_CHECK(P.enc[9].dim + P.audio_dim == 768, "predictor_condition: condition width %d != 768", P.enc[9].dim + P.audio_dim);
   Arena ar(ws, ws_bytes);
   const int Tq = tq_of(T);
-  float* cond_cl = ar.f32((size_t)B * Tq * 768);
+  float* cond_cl = ar.f32((size_t)B * Tq * P.cond_w);
   if (m.precision == 1 ? predictor_condition_cl_b(P, masked_motion, mask, audio, B, T, cond_cl, ar, s)
                        : predictor_condition_cl(P, masked_motion, mask, audio, B, T, cond_cl, ar, s)) return 1;
-  return launch_cl_to_ncl(cond_cl, 768, 0, condition, B, 768, Tq, s);
+  return launch_cl_to_ncl(cond_cl, P.cond_w, 0, condition, B, P.cond_w, Tq, s);
 }
 
 struct PredMem {
@@ -522,7 +524,7 @@ static int alloc_predmem(const Predictor& P, Arena& ar, int B, int Tq, bool bf, 
     pm.mem = ar.f32(Rm * DM);
     for (int l = 0; l < P.n_layers; ++l) pm.kv[l] = ar.f32(Rm * 2 * DM);
   } else {
-    pm.condb = (bf16_t*)ar.raw(Rm * 768 * 2);
+    pm.condb = (bf16_t*)ar.raw(Rm * P.cond_w * 2);
     pm.memb = (bf16_t*)ar.raw(Rm * DM * 2);
     for (int l = 0; l < P.n_layers; ++l) {
       pm.kv[l] = ar.raw(Rm * 2 * DM * 2);
@@ -537,13 +539,13 @@ static int predictor_memory(const Predictor& P, const float* cond_cl, int B, int
   PT_CHECK(Tq + 1 <= P.pe_rows, "sequence of %d latent steps exceeds the positional table (%d)", Tq, P.pe_rows - 1);
   const int Rm = B * Tq;
   if (!bf) {
-    if (lin(P.condi_emb, cond_cl, 768, Rm, pm.mem, DM, ACT_NONE, 1.f, s, P.pe + DM, Tq)) return 1;
+    if (lin(P.condi_emb, cond_cl, P.cond_w, Rm, pm.mem, DM, ACT_NONE, 1.f, s, P.pe + DM, Tq)) return 1;
     for (int l = 0; l < P.n_layers; ++l)
       if (lin(P.layers[l].ca_kv, pm.mem, DM, Rm, (float*)pm.kv[l], 2 * DM, ACT_NONE, 1.f, s)) return 1;
     return 0;
   }
-  if (launch_cvt_f32_bf16(cond_cl, 768, pm.condb, 768, Rm, 768, 768, s)) return 1;
-  if (lin_b(P.condi_emb, pm.condb, 768, Rm, nullptr, 0, pm.memb, DM, ACT_NONE, 1.f, s, P.pe + DM, Tq)) return 1;
+  if (launch_cvt_f32_bf16(cond_cl, P.cond_w, pm.condb, P.cond_w, Rm, P.cond_w, P.cond_w, s)) return 1;
+  if (lin_b(P.condi_emb, pm.condb, P.cond_w, Rm, nullptr, 0, pm.memb, DM, ACT_NONE, 1.f, s, P.pe + DM, Tq)) return 1;
   for (int l = 0; l < P.n_layers; ++l) {
     bf16_t* kvb = (bf16_t*)pm.kv[l];
     if (lin_b(P.layers[l].ca_kv, pm.memb, DM, Rm, nullptr, 0, kvb, 2 * DM, ACT_NONE, 1.f, s)) return 1;
@@ -572,12 +574,12 @@ int predictor_logits(Model& m, const int32_t* ids, const int64_t* label, const f
   const Predictor& P = *m.pred;
   const bool bf = m.precision == 1;
   Arena ar(ws, ws_bytes);
-  float* cond_cl = ar.f32((size_t)B * Tq * 768);
+  float* cond_cl = ar.f32((size_t)B * Tq * P.cond_w);
   PredMem pm;
   alloc_predmem(P, ar, B, Tq, bf, pm);
   TBufs tb = alloc_tbufs(ar, (size_t)B * Tq * P.groups, B, Tq * P.groups, bf);
   PT_CHECK(!ar.overflow, "predictor_logits: workspace too small (%zu given, %zu needed)", ws_bytes, ar.off);
-  if (launch_ncl_to_cl(condition, cond_cl, B, 768, Tq, 768, 0, 768, s)) return 1;
+  if (launch_ncl_to_cl(condition, cond_cl, B, P.cond_w, Tq, P.cond_w, 0, P.cond_w, s)) return 1;
   if (predictor_memory(P, cond_cl, B, Tq, bf, pm, s)) return 1;
   return predictor_pass(P, ids, label, pm, tb, B, Tq, bf, logits, s);
 }
@@ -594,14 +596,14 @@ int predictor_sample(Model& m, const int64_t* label, const float* condition, con
   const int N = Tq * P.groups, V = P.num_codes;
   const size_t R = (size_t)B * N;
   Arena ar(ws, ws_bytes);
-  float* cond_cl = ar.f32((size_t)B * Tq * 768);
+  float* cond_cl = ar.f32((size_t)B * Tq * P.cond_w);
   PredMem pm;
   alloc_predmem(P, ar, B, Tq, bf, pm);
   TBufs tb = alloc_tbufs(ar, R, B, N, bf);
   int* ids = (int*)ar.raw(R * sizeof(int));
   float* lg = logits_out ? nullptr : ar.f32(R * V);
   PT_CHECK(!ar.overflow, "predictor_sample: workspace too small (%zu given, %zu needed)", ws_bytes, ar.off);
-  if (launch_ncl_to_cl(condition, cond_cl, B, 768, Tq, 768, 0, 768, s)) return 1;
+  if (launch_ncl_to_cl(condition, cond_cl, B, P.cond_w, Tq, P.cond_w, 0, P.cond_w, s)) return 1;
   if (predictor_memory(P, cond_cl, B, Tq, bf, pm, s)) return 1;
   if (launch_fill_i32(ids, V, R, s)) return 1;
   for (int t = 0; t < steps; ++t) {

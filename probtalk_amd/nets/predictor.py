@@ -129,32 +129,39 @@ class TrainWrapper(TrainWrapperBaseClass):
         with torch.no_grad():
             _, qo_gt, _ = self.VQ.encode(gt_poses=gt_poses)
             state = qo_gt.loss
-        if self.text:
-            raise NotImplementedError("text conditioning (p_text) is off in config/transformer.json and not built")
         epoch_ratio = min(max(epoch / 99, 0.5), 1)
         for m in (self.AudEnc, self.Predictor):
             if next(m.parameters()).device.type != 'cuda':
                 m.cuda()
             m.train()
-        self._sync_dropout(self.AudEnc, self.Predictor)
-        # one dropout seed stream for the step, consumed in call order (AudEnc, then the decoder layers)
-        self.AudEnc.__dict__['_pt_seeds'] = self.Predictor.__dict__['_pt_seeds'] = self._seeds
+        mods = (self.AudEnc, self.TextEnc, self.Predictor) if self.text else (self.AudEnc, self.Predictor)
+        if self.text:
+            if next(self.TextEnc.parameters()).device.type != 'cuda':
+                self.TextEnc.cuda()
+            self.TextEnc.train()
+        self._sync_dropout(*mods)
+        # one dropout seed stream for the step, consumed in call order (AudEnc, TextEnc, then the decoder layers)
+        for m in mods:
+            m.__dict__['_pt_seeds'] = self._seeds
         if '_keep_scores' in bat:
             self.Predictor.decoder.__dict__['_pt_keep_scores'] = bat['_keep_scores'].to(dev)
         self.generator_optimizer.zero_grad()
         audio = self.AudEnc(aud)                                                            # predictor.py:243
-        pred_state = self.Predictor(input_poses, state, mask, id.reshape(-1), audio, None, epoch_ratio)   # :254
+        text = self.TextEnc(bat['text_feat'].to(dev).to(torch.float32)) if self.text else None          # :248-250
+        pred_state = self.Predictor(input_poses, state, mask, id.reshape(-1), audio, text, epoch_ratio)   # :254
         logits = pred_state['logits']
         loss = train_ops.CrossEntropy.apply(logits.reshape(-1, logits.shape[-1]).contiguous(),
                                             state.reshape(-1).to(torch.int64).contiguous())   # :261
         pa, pp = list(self.AudEnc.parameters()), list(self.Predictor.parameters())
+        pt = list(self.TextEnc.parameters()) if self.text else []
         multi = torch.distributed.is_available() and torch.distributed.is_initialized() \
             and torch.distributed.get_world_size() > 1
         if multi and self.__dict__.get('_reducer') is None:
             # one process per GPU in place of nn.DataParallel (to_parallel): mean gradient over ranks, rank 0's BN buffers.
             # Built before backward so that its hooks send each bucket while the earlier layers are still in backward
             from ..dist import GradientReducer
-            self._reducer = GradientReducer(pa + pp, list(self.AudEnc.buffers()) + list(self.Predictor.buffers()))
+            self._reducer = GradientReducer(pa + pp + pt, list(self.AudEnc.buffers()) + list(self.Predictor.buffers()) +
+                                            (list(self.TextEnc.buffers()) if self.text else []))
         loss.backward()
         max_norm = self.config.Train.max_gradient_norm
         if multi:
@@ -162,13 +169,20 @@ class TrainWrapper(TrainWrapperBaseClass):
             self._reducer.sync_buffers()
         grad_ae, coef_ae = train_ops.clip_grad_norm(pa, max_norm)
         grad_p, coef_p = train_ops.clip_grad_norm(pp, max_norm)
+        scal = [grad_ae, coef_ae, grad_p, coef_p]
+        if pt:
+            grad_te, coef_te = train_ops.clip_grad_norm(pt, max_norm)                  # predictor.py:272
+            scal += [grad_te, coef_te]
         if multi:
-            self._reducer.agree(grad_ae, coef_ae, grad_p, coef_p)
+            self._reducer.agree(*scal)
         coefs = {p: coef_ae for p in pa}
         coefs.update({p: coef_p for p in pp})
+        if pt:
+            coefs.update({p: coef_te for p in pt})
         self.generator_optimizer.step(coefs)
         self.AudEnc.invalidate()          # the packed inference weights are stale now
         self.Predictor.invalidate()
+        self.TextEnc.invalidate()
         loss_dict = {'logits': loss, 'loss': loss.item(), 'grad_ae': grad_ae.item(), 'grad_p': grad_p.item()}
         return None, loss_dict
 
@@ -182,9 +196,17 @@ class TrainWrapper(TrainWrapperBaseClass):
             return torch.cat([gt_poses[:, :self.each_dim[0]], gt_poses[:, -self.each_dim[3]:]], 1)
         return gt_poses
 
-    def _infer(self, aud, id, B, gt_poses, mask, noise=None, sync=True, seed=None):
+    def _infer(self, aud, id, B, gt_poses, mask, noise=None, sync=True, seed=None, text=None):
         gt_poses = self._select(gt_poses)
         aud = aud.repeat(B, 1, 1) if aud.shape[0] != B else aud
+        if self.text:
+            # predictor.py:415-416: text features repeated per sample and resized to the audio's frame count
+            if text is None:
+                raise RuntimeError("this predictor was built with p_text: pass the text features")
+            text = text.repeat(B, 1, 1) if text.shape[0] != B else text
+            text = interp_blend(text, aud.shape[2])
+        else:
+            text = None
         id = torch.as_tensor(id).to('cuda').reshape(-1)
         id = id.repeat(B) if id.numel() == 1 else id
         T = aud.shape[2]
@@ -195,7 +217,8 @@ class TrainWrapper(TrainWrapperBaseClass):
         start = time.time()
         input_poses = interp_blend(None, T, gt, mk, premask=False)  # gt_poses * mask
         audio = self.AudEnc(aud)
-        codes = self.Predictor(input_poses, None, mk, id, audio, None, 1, noise=noise, seed=seed)
+        tfeat = self.TextEnc(text) if text is not None else None
+        codes = self.Predictor(input_poses, None, mk, id, audio, tfeat, 1, noise=noise, seed=seed)
         pred_poses = self.VQ.decode_codes(codes)                    # quantize_all + transpose + decode
         pred_poses = interp_blend(pred_poses, T, input_poses, mk, premask=False)   # input_poses*mask + pred*(1-mask)
         if sync:
@@ -206,11 +229,11 @@ class TrainWrapper(TrainWrapperBaseClass):
         """predictor.py:398-448 -> (poses (B,C,T), seconds).  sync=False enqueues only (seconds ~ 0)."""
         assert self.args.infer, "train mode"
         self._eval()
-        poses, _, sec = self._infer(aud, id, B, gt_poses, mask, noise, sync, seed)
+        poses, _, sec = self._infer(aud, id, B, gt_poses, mask, noise, sync, seed, text=text)
         return poses, sec
 
     def infer_to_code(self, aud, text, id, B, gt_poses, mask, noise=None, seed=None, **kwargs):
         """predictor.py:597-647 -> (poses, codes (B,T',G), seconds)."""
         assert self.args.infer, "train mode"
         self._eval()
-        return self._infer(aud, id, B, gt_poses, mask, noise, seed=seed)
+        return self._infer(aud, id, B, gt_poses, mask, noise, seed=seed, text=text)

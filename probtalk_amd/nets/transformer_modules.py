@@ -254,8 +254,8 @@ class PredictorNet(_HandleOwner, nn.Module):
         super().__init__()
         if not transformer:
             raise NotImplementedError("the PixelCNN decoder (transformer=False) is not on the configured path")
-        if not motion_context or text is not None or audio is None or knn:
-            raise NotImplementedError("only motion_context=True, audio set, text=None, knn=False is on the configured path")
+        if not motion_context or audio is None or knn:
+            raise NotImplementedError("only motion_context=True, audio set, knn=False is on the configured path")
         if dim != 512 or enc_layers != 10:
             raise NotImplementedError("the HIP sequence is built for dim=512, enc_layers=10 (predictor.py:72)")
         self.dim = dim
@@ -270,6 +270,7 @@ class PredictorNet(_HandleOwner, nn.Module):
         self.is_transformer = transformer
         self.mot_dim = mot_dim
         self.n_classes = n_classes
+        self.text = text
         self.motion_embedding = nn.Conv1d(mot_dim + 1, dim // 4, 1, 1, padding=0)
         self.enc = nn.ModuleList()
         d = dim // 4
@@ -292,8 +293,16 @@ class PredictorNet(_HandleOwner, nn.Module):
         return [self.mot_dim, self.num_code, self.groups, self.n_classes, self.decoder.num_hidden_layers,
                 self.decoder.condi_dim - 512]
 
-    def condition(self, masked_motion, mask, audio):
-        """The part of forward before the decoder call (predictornet.py:87-100): (B,768,T') (inference sequence)."""
+    def _features(self, audio, text):
+        """Audio (and, with p_text set, text) condition features side by side, as predictornet.py:93-97 concatenates them."""
+        if (text is not None) != (self.text is not None):
+            raise RuntimeError("PredictorNet: text features must be passed exactly when the net was built with text=<name>")
+        return audio if text is None else torch.cat([audio, text], dim=1)
+
+    def condition(self, masked_motion, mask, audio, text=None):
+        """The part of forward before the decoder call (predictornet.py:87-100): (B, 768 | 1024 with text, T')
+        (inference sequence)."""
+        audio = self._features(audio, text)
         mm, mk, au = _cuda_f32(masked_motion), _cuda_f32(mask), _cuda_f32(audio)
         B, Cc, T = mm.shape
         if Cc != self.mot_dim or tuple(mk.shape) != (B, 1, T):
@@ -318,7 +327,7 @@ class PredictorNet(_HandleOwner, nn.Module):
         if self.training:
             # predictornet.py:87-103: motion-context encoder, cat with the audio features, decoder(state, ...) -> logits
             from .. import train_ops as T, training
-            mm, mk, au = _cuda_keep_grad(masked_motion), _cuda_keep_grad(mask), _cuda_keep_grad(audio)
+            mm, mk, au = _cuda_keep_grad(masked_motion), _cuda_keep_grad(mask), _cuda_keep_grad(self._features(audio, text))
             B, _, Tn = mm.shape
             motion, Tq = training.motion_context_train(_train_tensors(self), T.to_rows(torch.cat([mm, mk], dim=1)), B, Tn)
             if tuple(au.shape) != (B, self.decoder.condi_dim - 512, Tq):
@@ -326,7 +335,7 @@ class PredictorNet(_HandleOwner, nn.Module):
                                    f"got {tuple(au.shape)}")
             cond = torch.cat([motion, T.to_rows(au, au.shape[1])], dim=1).contiguous()
             return self.decoder._forward_rows(state, label, cond, B, Tq, epoch_ratio)
-        cond = self.condition(masked_motion, mask, audio)
+        cond = self.condition(masked_motion, mask, audio, text)
         return self.decoder.sample_good(label, cond, input_codes, T=self.T, noise=noise, seed=seed)
 
 
