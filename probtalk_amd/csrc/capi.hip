@@ -73,8 +73,8 @@ int scratch_for_current_device(void** out) {
 }
 
 // ---- run-time options (pt_common.h: Option).  Plain ints: set them before the calls they affect, from one thread.
-int g_opt[pt::OPT_COUNT] = {1, -1, 2048, 0, 0, 1};
-const char* const g_opt_name[pt::OPT_COUNT] = {"resid_bf16", "fused_tail", "small_rows", "row_tile", "attn_train_rowwise", "conv8"};
+int g_opt[pt::OPT_COUNT] = {1, -1, 2048, 0, 0, 1, 1};
+const char* const g_opt_name[pt::OPT_COUNT] = {"resid_bf16", "fused_tail", "small_rows", "row_tile", "attn_train_rowwise", "conv8", "store_overlap"};
 int find_option(const char* name) {
   if (name)
     for (int i = 0; i < pt::OPT_COUNT; ++i)

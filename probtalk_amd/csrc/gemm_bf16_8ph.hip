@@ -16,8 +16,17 @@
 // (vmcnt(8) = four half-tiles of 2 DMA instructions stay in flight) and is read five or six phases after its issue,
 // i.e. at least one phase and one barrier after every wave's retiring wait (RAW across the staggered halves).
 // The K-tile stream runs across output tiles (persistent workgroups): the next tile's first K-tiles land while the
-// current tile's accumulators are stored.  Stores share the vmcnt counter with the DMA, so a tile ends with vmcnt(0)
-// BEFORE its stores and the next tile's first K-tile issues no waits (everything it reads has landed by then).
+// current tile's accumulators are stored.  Stores share the vmcnt counter with the DMA (in-order retirement), so the
+// counted waits have to know how many stores sit between a half-tile and the wait:
+//   * plain bf16 output, interior tile, a successor tile exists: quadrant (0,0) is final after P1 of the last K-tile,
+//     (0,1) after P2, (1,1) after P3, (1,0) after P4.  Each leaves (4 store instructions per wave) at the head of the
+//     NEXT phase, under that phase's MFMAs; the waits of P3 / P4 count the 4 / 8 stores in (vmcnt(12) / vmcnt(16)), and
+//     the tile ends with vmcnt(20): the 16 stores and the two half-tiles of P3 / P4 may stay in flight, the next tile's
+//     first K-tile (last issued in P2) has landed.  Store counts are exact because the tile is interior (no lane or
+//     wave is predicated off).  Measured at configs[1]: 22.7 -> 21.5 ms per step over the 122 launches of this kernel;
+//   * every other tile (edges, fp32 / positional / residual epilogues, the last tile of a workgroup) ends with vmcnt(0)
+//     BEFORE its stores.
+// Either way the next tile's first K-tile issues no waits (everything it reads has landed by then).
 #include <cstdlib>
 
 #include "pt_common.h"
@@ -46,7 +55,7 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-__global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const int tiles_n, const int ntiles) {
+__global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const int tiles_n, const int ntiles, const int overlap) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int G = gridDim.x;
   int tile0;
@@ -136,8 +145,37 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
       }
     }
 
+    // An interior tile with a successor and a plain bf16 output stores each quadrant right after its last MFMA phase,
+    // between the phases of the last K-tile, instead of after the loop (see storeQ)
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const bool early = overlap && p.Cb && !p.C && !p.pe && !p.Res && tile + G < ntiles && tm * 256 + 256 <= p.M &&
+                       tn * 256 + 256 <= p.N;
+    // quadrant (mh, nh) = accumulators [mh*4 .. mh*4+3][nh*2, nh*2+1]: 4 store instructions of 16 rows x 32 bf16 per wave
+    auto storeQ = [&](int mh, int nh) {
+      int er = r, eq = q4;
+      asm volatile("" : "+v"(er), "+v"(eq));
+      const int j = nh * 2;
+      unsigned short* cb = p.Cb + (size_t)(tm * 256 + wr * 128 + mh * 64 + er) * p.ldcb + tn * 256 + wc * 64 + 16 * (j + (eq & 1)) + 8 * (eq >> 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 a0 = acc[mh * 4 + i][j], a1 = acc[mh * 4 + i][j + 1];
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a0[e] = a0[e] > 0.f ? a0[e] : 0.f;
+            a1[e] = a1[e] > 0.f ? a1[e] : 0.f;
+          }
+        }
+        const auto s0 = __builtin_amdgcn_permlane16_swap(pack_bf16(a0[0], a0[1]), pack_bf16(a1[0], a1[1]), false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(pack_bf16(a0[2], a0[3]), pack_bf16(a1[2], a1[3]), false, false);
+        const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+        *reinterpret_cast<u32x4*>(cb + (size_t)i * 16 * p.ldcb) = v;
+      }
+    };
+
     for (int t = 0; t < nt; ++t, cbuf ^= 1) {
       const unsigned char* sb = smem + cbuf * G8_STAGE;
+      const bool fl = early && t == nt - 1;
       auto readA = [&](int mh) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -152,9 +190,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
           for (int s = 0; s < 2; ++s)
             bfr[nh][j][s] = *reinterpret_cast<const bf16x8*>(sb + (2 + nh) * G8_HT + b_row0 + j * 2048 + aoff[s]);
       };
-      auto wait = [&]() {
+      // `stores` = early store instructions of this K-tile already in the queue: they are younger than the half-tile
+      // this wait retires, so the count grows by them and the DMA retires exactly where it does without them
+      auto wait = [&](int stores) {
         if (t > 0) {
           if (draining) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else if (fl && stores == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          else if (fl && stores == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         }
       };
@@ -175,21 +217,33 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
         __builtin_amdgcn_s_barrier();
       };
       // P1
-      readB(0); readA(0); issue(3); wait();
+      readB(0); readA(0); issue(3); wait(0);
       mma(0, 0);
       // P2
-      readB(1); issue(1); wait(); mma(0, 1);
+      readB(1); issue(1); wait(0);
+      if (fl) storeQ(0, 0);
+      mma(0, 1);
       // P3
-      readA(1); issue(0); wait(); mma(1, 1);
+      readA(1); issue(0); wait(4);
+      if (fl) storeQ(0, 1);
+      mma(1, 1);
       // P4
-      issue(2); wait(); mma(1, 0);
+      issue(2); wait(8);
+      if (fl) storeQ(1, 1);
+      mma(1, 0);
+    }
+    if (early) {
+      // the next tile's first K-tile issues no waits: its last half-tile (h1, issued in P2) must have landed.  Younger
+      // than it: 4 x 4 stores and the two half-tiles of P3 / P4 = 20 instructions
+      storeQ(1, 0);
+      asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      continue;
     }
 
     // ---- epilogue.  acc[i][j][e]: row m = m0 + wr*128 + i*16 + r, column n = n0 + wc*64 + j*16 + 4*q4 + e
     // (lane coordinates laundered so that the address arithmetic is not hoisted into the main loop's registers)
     int er = r, eq = q4;
     asm volatile("" : "+v"(er), "+v"(eq));
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int mw = tm * 256 + wr * 128, nw = tn * 256 + wc * 64;
     const int ncols = p.N > p.zero_to ? p.N : p.zero_to;
     if (p.pe || p.Res || p.relu || nw + 64 > p.N) {
@@ -268,7 +322,7 @@ int launch_gemm8(const GemmBigArgs& a, int cfg, hipStream_t s) {
   const int grid = ntiles < g8_num_cus ? ntiles : g8_num_cus;
   void* tok = nullptr;
   if (prof_is_on()) prof_record_begin(s, a.flops > 0 ? a.flops : 2.0 * a.M * a.N * a.K, cfg, &tok);
-  PT_LAUNCH(gemm8_kernel, dim3(grid), dim3(512), G8_SMEM, s, a, tiles_n, ntiles);
+  PT_LAUNCH(gemm8_kernel, dim3(grid), dim3(512), G8_SMEM, s, a, tiles_n, ntiles, option(OPT_STORE_OVERLAP));
   if (tok) prof_record_end(s, tok);
   return 0;
 }

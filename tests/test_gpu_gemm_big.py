@@ -188,3 +188,32 @@ def test_persistent_ln_epilogues_match_reference_and_repeat(M, K):
         else:
             assert torch.equal(out, first[0]) and torch.equal(xd, first[1]) and torch.equal(xb, first[2]) and \
                 torch.equal(xr, first[3]), f"run {rep} differs"
+
+
+# ---- bf16-only output of interior tiles with a successor: the quadrants are stored between the phases of the last
+# K-tile (store_overlap).  Same accumulators, same rounding: the result equals the stores-after-the-loop path bit for bit.
+@pytest.mark.parametrize("M,N,K,relu", [(75776, 2048, 512, 1), (75776, 1536, 512, 0), (40000, 1024, 128, 1),
+                                        (30001, 1536, 2048, 0), (66000, 376, 512, 0)])
+def test_early_quadrant_stores_equal_late_stores(M, N, K, relu):
+    L = _lib.lib()
+    A, W, bias, Np = _mk(M, N, K, 17)
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    ref = _ref64(Ad, Wd[:N], bd[:N])
+    if relu:
+        ref = ref.clamp_min(0)
+    scale = float(ref.abs().max())
+    ldc = N + 8
+    outs = []
+    try:
+        for mode in (1, 0, 1):
+            _lib.check(L.pt_set_option(b"store_overlap", mode))
+            Cb = torch.full((M, ldc), 7.0, device="cuda", dtype=torch.bfloat16)
+            _lib.check(L.pt_gemm_bf16(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, N, K, Np, None, 0, _lib.ptr(Cb), ldc, relu,
+                                      _lib.stream()))
+            torch.cuda.synchronize()
+            outs.append(Cb)
+    finally:
+        _lib.check(L.pt_set_option(b"store_overlap", 1))
+    assert float((outs[0][:, :N].double() - ref).abs().max()) / scale < 5e-3
+    assert bool((outs[0][:, N:] == 7.0).all())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
