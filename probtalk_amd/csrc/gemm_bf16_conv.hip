@@ -258,27 +258,42 @@ __global__ __launch_bounds__(512) void conv8_kernel(const GemmArgsB p, const uns
       }
       continue;
     }
+    // bf16 residual rows (indexed by OUTPUT row): the lane's 4 consecutive columns of each accumulator.  The loads are
+    // unconditional (rows past M read row M-1, columns past N read column 0: neither is stored) and run one 16-row
+    // block ahead of the adds: a load under a branch costs a vmcnt(0), i.e. one memory round trip, per load
+    auto out_row = [&](int m) {
+      if (plain_rows) return m;
+      const int b = m / p.Lgrid;
+      return b * p.Lout + (m - b * p.Lgrid) * p.out_stride + p.out_off;
+    };
+    u32x2 rv[2][4];
+    auto load_res = [&](int i, int buf) {
+      int m = mw + i * 16 + er;
+      m = m < p.M ? m : p.M - 1;
+      const unsigned short* rrow = p.ResB + (size_t)out_row(m) * p.ldr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = nw + j * 16 + 4 * eq;
+        rv[buf][j] = *reinterpret_cast<const u32x2*>(rrow + (n < p.N ? n : 0));
+      }
+    };
+    if (p.ResB) {
+      load_res(0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int m = mw + i * 16 + er;
       const bool live = m < p.M;
-      int orow = m;
-      if (!plain_rows) {
-        const int b = m / p.Lgrid;
-        orow = b * p.Lout + (m - b * p.Lgrid) * p.out_stride + p.out_off;
-      }
-      // bf16 residual rows (indexed by OUTPUT row): the lane's 4 consecutive columns of each accumulator
+      const int orow = out_row(m);
       if (p.ResB) {
+        if (i + 1 < 8) load_res(i + 1, (i + 1) & 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int n = nw + j * 16 + 4 * eq;
-          if (live && n < p.N) {
-            const u32x2 rv = *reinterpret_cast<const u32x2*>(p.ResB + (size_t)orow * p.ldr + n);
-            acc[i][j][0] += __builtin_bit_cast(float, rv[0] << 16);
-            acc[i][j][1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
-            acc[i][j][2] += __builtin_bit_cast(float, rv[1] << 16);
-            acc[i][j][3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
-          }
+          const u32x2 x = rv[i & 1][j];
+          acc[i][j][0] += __builtin_bit_cast(float, x[0] << 16);
+          acc[i][j][1] += __builtin_bit_cast(float, x[0] & 0xffff0000u);
+          acc[i][j][2] += __builtin_bit_cast(float, x[1] << 16);
+          acc[i][j][3] += __builtin_bit_cast(float, x[1] & 0xffff0000u);
         }
       }
 #pragma unroll

@@ -243,10 +243,10 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
           f32x4 xv[2][4];
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
-            const int m = m_base + (i + k) * 16 + er;
+            int m = m_base + (i + k) * 16 + er;
+            m = m < p.M ? m : p.M - 1;                       // unconditional loads (see the bf16 branch); row M-1 is never stored
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              xv[k][j] = m < p.M ? *reinterpret_cast<const f32x4*>(p.X + (size_t)m * 512 + n_base + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j) xv[k][j] = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * 512 + n_base + j * 16);
           }
 #pragma unroll
           for (int k = 0; k < 2; ++k)
@@ -258,31 +258,37 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
       } else {
         // bf16 residual stream (X == nullptr): the residual is the bf16 row this epilogue overwrites.  Loaded in the
         // store layout (a lane reads the 8 consecutive bf16 it will write: in place is safe) and un-paired with the
-        // same v_permlane16_swap; four 16-row blocks per round trip in the registers two fp32 blocks took.
-        constexpr int XB = 4;
-#pragma unroll
-        for (int i0 = 0; i0 < MT; i0 += XB) {
-          u32x4 xr[XB][2];
+        // same v_permlane16_swap.  Groups of two 16-row blocks, two groups in flight: group g+2 is requested as soon as
+        // group g has been added, so the loads stream instead of paying one round trip per group.
+        constexpr int XB = 2, NG = (MT + XB - 1) / XB;
+        u32x4 xr[2][XB][2];
+        auto load_grp = [&](int g, int buf) {
 #pragma unroll
           for (int k = 0; k < XB; ++k) {
-            if (i0 + k < MT) {
-              const int m = m_base + (i0 + k) * 16 + er;
+            if (g * XB + k < MT) {
+              // rows past M read row M-1 (never stored): an unconditional load keeps the group free of branches, and a
+              // branch per load costs a vmcnt(0), i.e. one memory round trip, per load
+              int m = m_base + (g * XB + k) * 16 + er;
+              m = m < p.M ? m : p.M - 1;
 #pragma unroll
               for (int jj = 0; jj < 2; ++jj) {
                 const int n = wave * 64 + 16 * (2 * jj + (eq & 1)) + 8 * (eq >> 1);
-                xr[k][jj] = m < p.M ? *reinterpret_cast<const u32x4*>(p.Cb + (size_t)m * p.ldcb + n) : u32x4{0u, 0u, 0u, 0u};
+                xr[buf][k][jj] = *reinterpret_cast<const u32x4*>(p.Cb + (size_t)m * p.ldcb + n);
               }
             }
           }
+        };
+        auto add_grp = [&](int g, int buf) {
 #pragma unroll
           for (int k = 0; k < XB; ++k) {
-            if (i0 + k < MT) {
+            if (g * XB + k < MT) {
 #pragma unroll
               for (int jj = 0; jj < 2; ++jj) {
-                const auto a0 = __builtin_amdgcn_permlane16_swap(xr[k][jj][0], xr[k][jj][2], false, false);   // -> x0, y0
-                const auto a1 = __builtin_amdgcn_permlane16_swap(xr[k][jj][1], xr[k][jj][3], false, false);   // -> x1, y1
-                f32x4& lo = acc[i0 + k][2 * jj];
-                f32x4& hi = acc[i0 + k][2 * jj + 1];
+                const u32x4 x = xr[buf][k][jj];
+                const auto a0 = __builtin_amdgcn_permlane16_swap(x[0], x[2], false, false);   // -> x0, y0
+                const auto a1 = __builtin_amdgcn_permlane16_swap(x[1], x[3], false, false);   // -> x1, y1
+                f32x4& lo = acc[g * XB + k][2 * jj];
+                f32x4& hi = acc[g * XB + k][2 * jj + 1];
                 lo[0] += __builtin_bit_cast(float, a0[0] << 16);
                 lo[1] += __builtin_bit_cast(float, a0[0] & 0xffff0000u);
                 lo[2] += __builtin_bit_cast(float, a1[0] << 16);
@@ -292,9 +298,16 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
                 hi[2] += __builtin_bit_cast(float, a1[1] << 16);
                 hi[3] += __builtin_bit_cast(float, a1[1] & 0xffff0000u);
               }
-              PT_PIN_BLOCK(i0 + k);
+              PT_PIN_BLOCK(g * XB + k);
             }
           }
+        };
+        load_grp(0, 0);
+        if constexpr (NG > 1) load_grp(1, 1);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          add_grp(g, g & 1);
+          if (g + 2 < NG) load_grp(g + 2, g & 1);
         }
       }
     }
