@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
     if constexpr (EPI != EPI_STD) {
       // LayerNorm over the 512 columns of a row: lane partials -> 4 lanes of a row (eq) -> 8 waves through LDS.
       // The partial sums cross the two staggered halves, so waves 0-3 wait for waves 4-7 here and the stagger is
-      // re-established after the epilogue.  Means / variances are re-read from LDS per block (no register arrays).
+      // re-established after the epilogue.
       if (grp == 0) __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
@@ -348,18 +348,23 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int e = 0; e < 4; ++e) s += acc[i][j][e];
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
+        s = row_lanes_sum(s);
         if (eq == 0) red[wave * 160 + i * 16 + er] = s;
         PT_PIN_BLOCK(i);
       }
       __builtin_amdgcn_s_barrier();
+      // the 8 per-wave partials of a row: each of the row's 4 lanes reads two of them (one ds_read2), the lane sum does
+      // the rest.  All MT blocks' reads go out in one batch (independent, one wait) instead of one dependent LDS round
+      // trip per block; the means stay in registers for the last pass
+      float mean_[MT], rstd_[MT];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        float tot = 0.f;
+        const float* pr = red + 2 * eq * 160 + i * 16 + er;
+        mean_[i] = row_lanes_sum(pr[0] + pr[160]) * (1.f / 512.f);
+      }
 #pragma unroll
-        for (int w = 0; w < 8; ++w) tot += red[w * 160 + i * 16 + er];
-        const float mean = tot * (1.f / 512.f);
+      for (int i = 0; i < MT; ++i) {
+        const float mean = mean_[i];
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -368,8 +373,7 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
             const float d = acc[i][j][e] - mean;
             s += d * d;
           }
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
+        s = row_lanes_sum(s);
         if (eq == 0) red[8 * 160 + wave * 160 + i * 16 + er] = s;
         PT_PIN_BLOCK(i);
       }
@@ -378,14 +382,12 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
       __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        float tot = 0.f, totq = 0.f;
+        const float* pr = red + 8 * 160 + 2 * eq * 160 + i * 16 + er;
+        rstd_[i] = __builtin_amdgcn_rsqf(row_lanes_sum(pr[0] + pr[160]) * (1.f / 512.f) + 1e-5f);
+      }
 #pragma unroll
-        for (int w = 0; w < 8; ++w) {
-          tot += red[w * 160 + i * 16 + er];
-          totq += red[8 * 160 + w * 160 + i * 16 + er];
-        }
-        const float mean = tot * (1.f / 512.f);
-        const float rstd = __builtin_amdgcn_rsqf(totq * (1.f / 512.f) + 1e-5f);
+      for (int i = 0; i < MT; ++i) {
+        const float mean = mean_[i], rstd = rstd_[i];
         const float nmr = -mean * rstd;
         const float* gp = tab + n_base;
         if constexpr (EPI == EPI_LNMOD) gp += cls[i] * 1024;

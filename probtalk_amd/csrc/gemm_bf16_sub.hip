@@ -265,8 +265,7 @@ __global__ __launch_bounds__(256) void sublayer_kernel(const SubArgs p, const in
     for (int nb = 0; nb < 32; ++nb)
 #pragma unroll
       for (int e = 0; e < 4; ++e) s += A[nb][e];
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
+    s = row_lanes_sum(s);
     mean = s * (1.f / 512.f);
     float v = 0.f;
 #pragma unroll
@@ -276,8 +275,7 @@ __global__ __launch_bounds__(256) void sublayer_kernel(const SubArgs p, const in
         const float d = A[nb][e] - mean;
         v += d * d;
       }
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
+    v = row_lanes_sum(v);
     rstd = __builtin_amdgcn_rsqf(v * (1.f / 512.f) + 1e-5f);
   };
 
@@ -325,10 +323,8 @@ __global__ __launch_bounds__(256) void sublayer_kernel(const SubArgs p, const in
               s1 += v;
               s2 = __builtin_fmaf(v, v, s2);
             }
-          s1 += __shfl_xor(s1, 16);
-          s2 += __shfl_xor(s2, 16);
-          s1 += __shfl_xor(s1, 32);
-          s2 += __shfl_xor(s2, 32);
+          s1 = row_lanes_sum(s1);
+          s2 = row_lanes_sum(s2);
           mean = s1 * (1.f / 512.f);
           const float var = __builtin_fmaf(-mean, mean, s2 * (1.f / 512.f));
           rstd = __builtin_amdgcn_rsqf((var > 0.f ? var : 0.f) + 1e-5f);
@@ -423,10 +419,8 @@ __global__ __launch_bounds__(256) void sublayer_kernel(const SubArgs p, const in
           }
         }
         if (mb == 0) fetch_residual(1);
-        s1 += __shfl_xor(s1, 16);
-        s2 += __shfl_xor(s2, 16);
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
+        s1 = row_lanes_sum(s1);
+        s2 = row_lanes_sum(s2);
         const float mean = s1 * (1.f / 512.f);
         const float var = __builtin_fmaf(-mean, mean, s2 * (1.f / 512.f));
         const float rstd = __builtin_amdgcn_rsqf((var > 0.f ? var : 0.f) + 1e-5f);

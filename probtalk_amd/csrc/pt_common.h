@@ -169,4 +169,21 @@ int launch_pq_search(const float* z_cl, int ldz, const float* codebooks, int row
 int launch_pq_gather(const void* idx, int idx_is_i64, const float* codebooks, int rows, int G, int D, int K,
                      float* q_cl, int ldq, int zero_to, hipStream_t s);
 
+// Sum over the four lanes {l, l^16, l^32, l^48} (the lanes that share an output row of a 16x16 MFMA accumulator), the
+// same in all four.  v_permlane16_swap / v_permlane32_swap on a register paired with itself are the xor-16 / xor-32
+// butterflies as plain VALU moves: no trip through the LDS crossbar (ds_bpermute, which __shfl_xor compiles to, costs a
+// lgkmcnt wait per step), and the same bits (each step adds the same two values).
+__device__ __forceinline__ float row_lanes_sum(float s) {
+  // the pair's elements go through scalars: __builtin_bit_cast applied to a vector element directly reads element 0
+  // for both (clang 20 / ROCm 7.2)
+  const unsigned u = __builtin_bit_cast(unsigned, s);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned a0 = a[0], a1 = a[1];
+  const float t = __builtin_bit_cast(float, a0) + __builtin_bit_cast(float, a1);
+  const unsigned w = __builtin_bit_cast(unsigned, t);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  const unsigned b0 = b[0], b1 = b[1];
+  return __builtin_bit_cast(float, b0) + __builtin_bit_cast(float, b1);
+}
+
 }  // namespace pt
