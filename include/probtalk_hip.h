@@ -260,6 +260,12 @@ int pt_train_add(const float* a, const float* b, float* out, size_t n, void* str
  * counter = the EMA modules' call count including this call.  rows >= K required. */
 int pt_train_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw,
                     float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, void* stream);
+/* The same with share_code=True (vqvae_modules.py:496-512): the chunks of all G groups update ONE codebook.  counts [K] and
+ * dw [K,D] are scratch; cs_hidden [K], dw_hidden [K,D], emb [K,D] are ema_cluster_size.hidden, ema_dw.hidden and
+ * embeddings_0.  Dead codes are re-seeded from the first K chunks in group-major order (all rows of group 0, then group
+ * 1, ...: line 498's flat_x); the EMA state is NOT reset (the share_code branch has no lines 529-532).  rows*G >= K. */
+int pt_train_pq_ema_shared(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw,
+                           float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, void* stream);
 /* VectorQuantizerEMA.forward train branch (vqvae_modules.py:323-334), the legacy single codebook of s2g_body_vq: the same
  * EMA update for ONE codebook [K, D] without dead-code re-seeding; any number of latent rows; K may exceed 1024. */
 int pt_train_vq_ema(const float* z, int ldz, const int64_t* idx, int rows, int D, int K, float* counts, float* dw,

@@ -90,15 +90,17 @@ def adamw_step(p, g, m, v, step, lr, betas=(0.9, 0.99), eps=1e-8, wd=1e-2):
 
 
 # ------------------------------------------------------------------------------------------------ PQ-VAE train step
-def pq_train(sd, p, z, groups, commitment_cost=0.25, decay=0.99, eps=1e-5, counter=1):
-    """ProductQuantization.forward, training branch, share_code False (vqvae_modules.py:470-487,495-544).
-    -> (quantized with straight-through gradient (B,C,W), commitment loss, indices (BW, G), updated buffers)."""
+def pq_train(sd, p, z, groups, commitment_cost=0.25, decay=0.99, eps=1e-5, counter=1, share_code=False):
+    """ProductQuantization.forward, training branch (vqvae_modules.py:470-487,495-544; share_code: 496-512).
+    -> (quantized with straight-through gradient (B,C,W), commitment loss, indices (BW, G), updated buffers).
+    share_code: every group searches its own buffer embeddings_i (they alias one tensor only until the module is moved
+    or loaded), the EMA state and embeddings_0 are the only buffers updated, and dead codes keep their EMA state."""
     B, C, W = z.shape
     D = C // groups
     x = z.permute(0, 2, 1)
     flat = x.reshape(-1, groups, D)
     K = sd[f"{p}embeddings_0"].shape[0]
-    assert flat.shape[0] >= K, "the noisy re-tiling of short batches (571-580) is not restated"
+    assert flat.shape[0] * (groups if share_code else 1) >= K, "the noisy re-tiling of short batches (571-580) is not restated"
     idx, q, new = [], [], {}
     for i in range(groups):
         emb = sd[f"{p}embeddings_{i}"]
@@ -108,7 +110,23 @@ def pq_train(sd, p, z, groups, commitment_cost=0.25, decay=0.99, eps=1e-5, count
     quantized = torch.cat(q, dim=-1)
     with torch.no_grad():
         corr = 1 - decay ** counter
-        for i in range(groups):
+        if share_code:
+            all_idx = torch.stack(idx, dim=0).reshape(-1)                           # line 497: group-major
+            all_x = flat.detach().permute(1, 0, 2).reshape(-1, D)                   # line 498
+            enc = F.one_hot(all_idx, K).to(flat.dtype)
+            cs_h = sd[f"{p}ema_cluster_size.hidden"].clone()
+            cs_h.sub_((cs_h - enc.sum(0)) * (1 - decay))
+            cs = cs_h / corr
+            n = cs.sum()
+            cs = (cs + eps) / (n + K * eps) * n
+            dw_h = sd[f"{p}ema_dw.hidden"].clone()
+            dw_h.sub_((dw_h - enc.t() @ all_x) * (1 - decay))
+            normalised = (dw_h / corr) / cs.reshape(-1, 1)
+            usage = (cs.view(K, 1) >= 1.0).float()
+            new[f"{p}ema_dw.hidden"] = dw_h
+            new[f"{p}ema_cluster_size.hidden"] = cs_h
+            new[f"{p}embeddings_0"] = usage * normalised + (1 - usage) * all_x[:K]
+        for i in range(groups if not share_code else 0):
             enc = F.one_hot(idx[i], K).to(flat.dtype)
             cs_h = sd[f"{p}ema_cluster_size.{i}.hidden"].clone()
             cs_h.sub_((cs_h - enc.sum(0)) * (1 - decay))

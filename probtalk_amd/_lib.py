@@ -85,6 +85,7 @@ def _proto(lib):
     lib.pt_train_adamw.argtypes = [vp, vp, vp, vp, sz, vp, f, f, f, f, f, i, vp]
     lib.pt_train_add.argtypes = [vp, vp, vp, sz, vp]
     lib.pt_train_pq_ema.argtypes = [vp, i, vp, i, i, i, i, vp, vp, vp, vp, vp, f, f, i, vp]
+    lib.pt_train_pq_ema_shared.argtypes = lib.pt_train_pq_ema.argtypes
     lib.pt_train_vq_ema.argtypes = [vp, i, vp, i, i, i, vp, vp, vp, vp, vp, f, f, i, vp]
     lib.pt_train_vq_losses.argtypes = [vp, i, vp, i, i, i, i, vp, vp, i, f, vp, vp, i, vp]
     lib.pt_train_masked_l1_losses.argtypes = [vp, i, vp, i, vp, f, i, i, i, vp, vp, i, vp, vp, i, vp]
@@ -113,7 +114,7 @@ EXPORTS = [
     "pt_train_modsilu_fwd", "pt_train_modsilu_bwd", "pt_train_attention_fwd", "pt_train_attention_bwd",
     "pt_train_cross_entropy", "pt_train_bn_fwd", "pt_train_bn_bwd", "pt_train_act_bwd", "pt_train_gate_fwd",
     "pt_train_gate_bwd", "pt_train_embed_bwd", "pt_train_dropout", "pt_train_sumsq", "pt_train_clip_coef",
-    "pt_train_adamw", "pt_train_add", "pt_train_pq_ema", "pt_train_vq_ema", "pt_train_vq_losses", "pt_train_masked_l1_losses", "pt_train_sqdiff", "pt_train_commit_bwd",
+    "pt_train_adamw", "pt_train_add", "pt_train_pq_ema", "pt_train_pq_ema_shared", "pt_train_vq_ema", "pt_train_vq_losses", "pt_train_masked_l1_losses", "pt_train_sqdiff", "pt_train_commit_bwd",
     "pt_set_option", "pt_get_option",
 ]
 

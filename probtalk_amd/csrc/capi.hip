@@ -502,6 +502,10 @@ int pt_train_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G
                     float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, void* stream) {
   return launch_pq_ema(z, ldz, idx, rows, G, D, K, counts, dw, cs_hidden, dw_hidden, emb, decay, eps, counter, (hipStream_t)stream, 1);
 }
+int pt_train_pq_ema_shared(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw,
+                           float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, void* stream) {
+  return launch_pq_ema(z, ldz, idx, rows, G, D, K, counts, dw, cs_hidden, dw_hidden, emb, decay, eps, counter, (hipStream_t)stream, 2);
+}
 int pt_train_vq_ema(const float* z, int ldz, const int64_t* idx, int rows, int D, int K, float* counts, float* dw,
                     float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, void* stream) {
   return launch_pq_ema(z, ldz, idx, rows, 1, D, K, counts, dw, cs_hidden, dw_hidden, emb, decay, eps, counter, (hipStream_t)stream, 0);

@@ -1164,18 +1164,20 @@ int launch_add(const float* a, const float* b, float* out, size_t n, hipStream_t
 // ---------------------------------------------------------------------------
 // EMA codebook statistics: counts[g][k] = #rows assigned, dw[g][k][:] = sum of their latent chunks (the reference's
 // one_hot^T . flat_x, vqvae_modules.py:515-520).  One wave per (row, group).
+// shared = 1 (share_code, 496-505): every group's chunks count towards the one code book, statistics [K] and [K][D].
 __global__ __launch_bounds__(256) void pq_ema_accum_kernel(const float* __restrict__ z, int ldz, const int64_t* __restrict__ idx,
                                                            int rows, int G, int D, int K, float* __restrict__ counts,
-                                                           float* __restrict__ dw) {
+                                                           float* __restrict__ dw, int shared) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (size_t w = (size_t)blockIdx.x * 4 + wave; w < (size_t)rows * G; w += (size_t)gridDim.x * 4) {
     const int row = (int)(w / G), g = (int)(w % G);
     const int64_t k = idx[(size_t)row * G + g];
     if (k < 0 || k >= K) continue;
-    float* dst = dw + ((size_t)g * K + k) * D;
+    const int gs = shared ? 0 : g;
+    float* dst = dw + ((size_t)gs * K + k) * D;
     const float* src = z + (size_t)row * ldz + g * D;
     for (int d = lane; d < D; d += 64) atomicAdd(dst + d, src[d]);
-    if (lane == 0) atomicAdd(counts + (size_t)g * K + k, 1.f);
+    if (lane == 0) atomicAdd(counts + (size_t)gs * K + k, 1.f);
   }
 }
 // hidden -= (hidden - value)(1 - decay); average = hidden / (1 - decay^counter); Laplace smoothing of the cluster sizes;
@@ -1185,8 +1187,11 @@ __global__ __launch_bounds__(1024) void pq_ema_finish_kernel(const float* __rest
                                                              const float* __restrict__ z, int ldz, int D, int K,
                                                              float* __restrict__ cs_hidden, float* __restrict__ dw_hidden,
                                                              float* __restrict__ emb, float one_minus_decay, float eps,
-                                                             float corr, int reseed) {
-  // reseed = 1: ProductQuantization (dead codes re-seeded, 529-534); 0: VectorQuantizerEMA (323-334, no re-seeding).
+                                                             float corr, int reseed, int rows) {
+  // reseed = 1: ProductQuantization (dead codes re-seeded and their EMA state reset, 525-534); 0: VectorQuantizerEMA
+  // (323-334, no re-seeding); 2: ProductQuantization with share_code (509-512): dead codes of the one code book are
+  // re-seeded from the first K chunks of the group-major flat_x of line 498 (chunk k = group k / rows, row k % rows), the
+  // EMA state is kept.
   // A thread walks codes k, k + blockDim.x, ... (code books larger than one workgroup).
   __shared__ float red[16];
   const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1207,33 +1212,36 @@ __global__ __launch_bounds__(1024) void pq_ema_finish_kernel(const float* __rest
     const float avg = h / corr;
     const float sm = (avg + eps) / (n + (float)K * eps) * n;
     const bool used = !reseed || sm >= 1.0f;
+    const int seed_g = reseed == 2 ? k / rows : g, seed_row = reseed == 2 ? k - seed_g * rows : k;
     for (int d = 0; d < D; ++d) {
       const size_t o = ((size_t)g * K + k) * D + d;
       float hd = dw_hidden[o];
       hd -= (hd - dw[o]) * one_minus_decay;
       const float nrm = (hd / corr) / sm;
-      const float rnd = reseed ? z[(size_t)k * ldz + g * D + d] : 0.f;
-      dw_hidden[o] = used ? hd : rnd;
+      const float rnd = reseed ? z[(size_t)seed_row * ldz + seed_g * D + d] : 0.f;
+      dw_hidden[o] = (used || reseed == 2) ? hd : rnd;
       emb[o] = used ? nrm : rnd;
     }
-    cs_hidden[(size_t)g * K + k] = used ? h : 1.0f;
+    cs_hidden[(size_t)g * K + k] = (used || reseed == 2) ? h : 1.0f;
   }
 }
 int launch_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw,
                   float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, hipStream_t s, int reseed) {
   PT_CHECK(z && idx && counts && dw && cs_hidden && dw_hidden && emb && G > 0 && D > 0 && K > 0, "pq_ema: bad argument");
-  PT_CHECK(!reseed || rows >= K, "pq_ema: %d latent rows < %d codes (the reference's noisy re-tiling of short batches, "
-                                 "vqvae_modules.py:573-577, is not built)", rows, K);
+  PT_CHECK(!reseed || (reseed == 2 ? (long long)rows * G : (long long)rows) >= K,
+           "pq_ema: %d latent rows < %d codes (the reference's noisy re-tiling of short batches, vqvae_modules.py:573-577, "
+           "is not built)", rows, K);
   PT_CHECK(counter >= 1 && decay > 0.f && decay < 1.f, "pq_ema: bad decay / counter");
-  PT_HIP(hipMemsetAsync(counts, 0, sizeof(float) * G * K, s));
-  PT_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)G * K * D, s));
+  const int shared = reseed == 2, Gs = shared ? 1 : G;            // statistics and state of ONE code book when shared
+  PT_HIP(hipMemsetAsync(counts, 0, sizeof(float) * Gs * K, s));
+  PT_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Gs * K * D, s));
   const size_t waves = (size_t)rows * G;
   PT_LAUNCH(pq_ema_accum_kernel, dim3((unsigned)std::min<size_t>((waves + 3) / 4, 65535)), dim3(256), 0, s, z, ldz, idx, rows, G,
-            D, K, counts, dw);
+            D, K, counts, dw, shared);
   const float omd = (float)(1.0 - (double)decay);
   const float corr = (float)(1.0 - std::pow((double)decay, (double)counter));
-  PT_LAUNCH(pq_ema_finish_kernel, dim3(G), dim3(std::min((K + 63) / 64 * 64, 1024)), 0, s, counts, dw, z, ldz, D, K, cs_hidden,
-            dw_hidden, emb, omd, eps, corr, reseed);
+  PT_LAUNCH(pq_ema_finish_kernel, dim3(Gs), dim3(std::min((K + 63) / 64 * 64, 1024)), 0, s, counts, dw, z, ldz, D, K, cs_hidden,
+            dw_hidden, emb, omd, eps, corr, reseed, rows);
   return 0;
 }
 

@@ -210,8 +210,6 @@ class ProductQuantization(_QuantizerBase):
     def __init__(self, embedding_dim, num_embeddings, commitment_cost, decay, epsilon=1e-5, num_chunks=8,
                  share_code=False, **kwargs):
         super().__init__()
-        if share_code:
-            raise NotImplementedError("share_code=True is not on the configured path (config/vq.json:44)")
         self.num_embeddings = num_embeddings
         self.commitment_cost = commitment_cost
         self.epsilon = epsilon
@@ -220,6 +218,18 @@ class ProductQuantization(_QuantizerBase):
         self.embedding_dim = embedding_dim // num_chunks
         self.ema_dw = nn.ModuleList()
         self.ema_cluster_size = nn.ModuleList()
+        if share_code:
+            # vqvae_modules.py:452-459: ONE tensor registered under all G buffer names (G state_dict entries), one EMA
+            # pair.  As in the reference, the names stop aliasing once the module is moved to a device or loaded from a
+            # checkpoint (nn.Module handles every buffer name on its own); training then updates embeddings_0 only
+            # (line 512) while group i keeps searching embeddings_i.
+            emb = torch.empty(num_embeddings, self.embedding_dim)
+            nn.init.xavier_uniform_(emb)
+            for i in range(num_chunks):
+                self.register_buffer("embeddings_{}".format(i), emb)
+            self.ema_dw = ExponentialMovingAverage(emb, decay)
+            self.ema_cluster_size = ExponentialMovingAverage(torch.zeros((num_embeddings,)), decay)
+            return
         for i in range(num_chunks):
             emb = torch.empty(num_embeddings, self.embedding_dim)
             nn.init.xavier_uniform_(emb)
@@ -251,6 +261,14 @@ class ProductQuantization(_QuantizerBase):
         cb = torch.stack([getattr(self, n) for n in self._codebook_names()]).contiguous()
         z = T.to_rows(x, Cc)
         q, loss, idx = T.PQQuantizeTrain.apply(z, cb, self.commitment_cost)
+        if self.share_code:
+            self.ema_cluster_size.counter += 1
+            self.ema_dw.counter += 1
+            T.pq_ema_update_shared(z.detach(), idx, G, self.ema_cluster_size.hidden, self.ema_dw.hidden, self.embeddings_0,
+                                   self.ema_dw.decay, self.epsilon, self.ema_dw.counter)
+            self.__dict__["_pt_cb"] = None
+            self.__dict__["_pt_last_indices"] = idx.view(B, W, G)
+            return QuantizationOutput(T.RowsToNCL.apply(q, B, Cc, W), loss)
         cs = torch.stack([m.hidden for m in self.ema_cluster_size]).contiguous()
         dw = torch.stack([m.hidden for m in self.ema_dw]).contiguous()
         for m in list(self.ema_cluster_size) + list(self.ema_dw):

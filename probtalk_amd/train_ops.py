@@ -476,6 +476,16 @@ def pq_ema_update(z, idx, cs_hidden, dw_hidden, emb, decay, eps, counter):
                             ptr(dw_hidden), ptr(emb), float(decay), float(eps), int(counter), stream()))
 
 
+def pq_ema_update_shared(z, idx, G, cs_hidden, dw_hidden, emb, decay, eps, counter):
+    """share_code=True (vqvae_modules.py:496-512): the chunks of all G groups update the ONE code book in place:
+    cs_hidden [K], dw_hidden [K,D], emb [K,D]; z rows [B*W, G*D], idx (B*W, G)."""
+    L = _lib.lib()
+    K, D = emb.shape
+    counts, dw = _empty(K), _empty(K, D)
+    check(L.pt_train_pq_ema_shared(ptr(z), z.shape[1], ptr(idx), z.shape[0], G, D, K, ptr(counts), ptr(dw), ptr(cs_hidden),
+                                   ptr(dw_hidden), ptr(emb), float(decay), float(eps), int(counter), stream()))
+
+
 def vq_ema_update(z, idx, cs_hidden, dw_hidden, emb, decay, eps, counter):
     """VectorQuantizerEMA's EMA codebook update (vqvae_modules.py:323-334, no re-seeding) in place on cs_hidden [K],
     dw_hidden [K,D], emb [K,D]; z rows [B*W, ld] are the encoder output of this step, idx (B*W, 1) its codes."""

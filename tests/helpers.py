@@ -141,3 +141,14 @@ def refiner_train_case(tag=None):
     mask[1, :, 10:40] = 1
     vq = gt + 0.3 * make_input(f"rtrain{tag}.vq", (B, 376, T))
     return aud, gt * mask + vq * (1 - mask), gt, mask, torch.tensor([1, 3])
+
+
+def share_code_case():
+    """Inputs of tests/golden/pq_share_code_b12_w22.npz (tools/make_golden_share_code.py): the initial code book of all
+    four groups, three latent batches (B=12, C=512, W=22; two train steps + one eval), the two upstream gradients."""
+    from probtalk_amd.weights import make_input
+    B, C, W, K, G = 12, 512, 22, 1024, 4
+    cb = (make_input("pqshare.codebook", (K, C // G)) * 0.05).contiguous()
+    xs = [(make_input(f"pqshare.x{i}", (B, C, W)) * 0.05).contiguous() for i in range(3)]
+    ws = [make_input(f"pqshare.w{i}", (B, C, W)) for i in range(2)]
+    return cb, xs, ws
