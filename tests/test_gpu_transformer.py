@@ -157,6 +157,20 @@ def test_interp_blend(Tin, Tout):
     assert rel_err(out.cpu(), gt * mask + ref * (1 - mask)) < 2e-6
 
 
+@pytest.mark.parametrize("T", [300, 30, 7])
+def test_interp_blend_streaming_and_odd_lengths(T):
+    """T_in == T_out and a blend without prediction: the 16-byte streaming kernel (T % 4 == 0) and the per-frame kernel
+    (odd lengths) give the exact blend."""
+    from probtalk_amd.nets.transformer_modules import interp_blend
+    pred = make_input("ib2.pred", (5, 376, T))
+    gt = make_input("ib2.gt", (5, 376, T))
+    mask = (make_input("ib2.mask", (5, 1, T), "uniform") > 0.5).float()
+    assert torch.equal(interp_blend(pred.cuda(), T).cpu(), pred)
+    assert torch.equal(interp_blend(pred.cuda(), T, gt.cuda(), mask.cuda(), premask=False).cpu(), gt * mask + pred * (1 - mask))
+    assert torch.equal(interp_blend(None, T, gt.cuda(), mask.cuda(), premask=False).cpu(), gt * mask)
+    assert torch.equal(interp_blend(pred.cuda(), T, gt.cuda(), mask.cuda(), premask=True).cpu(), (gt * mask) * mask + pred * (1 - mask))
+
+
 def test_maskgit_schedule_edge_cases():
     """one-pass decoding (T=1) resolves everything; ties in confidence keep reference semantics."""
     g = golden("predictor_b2_t88.npz")
