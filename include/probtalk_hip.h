@@ -305,7 +305,7 @@ int pt_postprocess_poses(const float* pred, int B, int T, const float* mean, con
  *   "row_tile"           0 (default) the N = 512 row kernel picks its tile height; 2 | 4 | 8 | 10 forces 16 x that many rows
  *   "attn_train_rowwise" 1 = training attention on the row-wise kernels whatever the shape (default 0)
  *   "conv8"              1 (default) conv stacks of the bf16 mode on the phase-pipelined LDS-DMA tap-GEMM where it applies
- *   "store_overlap"      1 (default) the 256 x 256 GEMM stores a bf16 tile's quadrants between the phases of its last
+ *   "store_overlap"      1 (default) the 256 x 256 GEMM stores a bf16 tile's upper half between the phases of its last
  *                        K-tile; 0 = after the loop (same bits either way)
  * Unknown names and out-of-range values are errors (non-zero return, pt_last_error). */
 int pt_set_option(const char* name, int value);

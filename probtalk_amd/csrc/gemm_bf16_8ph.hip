@@ -18,12 +18,15 @@
 // The K-tile stream runs across output tiles (persistent workgroups): the next tile's first K-tiles land while the
 // current tile's accumulators are stored.  Stores share the vmcnt counter with the DMA (in-order retirement), so the
 // counted waits have to know how many stores sit between a half-tile and the wait:
-//   * plain bf16 output, interior tile, a successor tile exists: quadrant (0,0) is final after P1 of the last K-tile,
-//     (0,1) after P2, (1,1) after P3, (1,0) after P4.  Each leaves (4 store instructions per wave) at the head of the
-//     NEXT phase, under that phase's MFMAs; the waits of P3 / P4 count the 4 / 8 stores in (vmcnt(12) / vmcnt(16)), and
-//     the tile ends with vmcnt(20): the 16 stores and the two half-tiles of P3 / P4 may stay in flight, the next tile's
-//     first K-tile (last issued in P2) has landed.  Store counts are exact because the tile is interior (no lane or
-//     wave is predicated off).  Measured at configs[1]: 22.7 -> 21.5 ms per step over the 122 launches of this kernel;
+//   * plain bf16 output, interior tile, a successor tile exists: the upper half of the tile (mh = 0, quadrants (0,0) and
+//     (0,1)) is final after P2 of the last K-tile.  Its 8 store instructions per wave leave at the head of P3 and P4 (4
+//     each: two 16-row blocks x both column halves, so every row's 128-byte line is written by two back-to-back
+//     instructions), under those phases' MFMAs; the lower half (final after P4) follows the loop.  P4's wait counts the 4
+//     stores in (vmcnt(12)) and the tile ends with vmcnt(20): the 16 stores and the two half-tiles of P3 / P4 may stay in
+//     flight, the next tile's first K-tile (last issued in P2) has landed.  Store counts are exact because the tile is
+//     interior (no lane or wave is predicated off).  A/B on one box at configs[1], over the 122 launches of this kernel
+//     per step: 23.4 ms without, 21.8 ms storing each quadrant one phase after its last MFMA (half lines in different
+//     phases), 20.7 ms this way;
 //   * every other tile (edges, fp32 / positional / residual epilogues, the last tile of a workgroup) ends with vmcnt(0)
 //     BEFORE its stores.
 // Either way the next tile's first K-tile issues no waits (everything it reads has landed by then).
@@ -145,31 +148,33 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
       }
     }
 
-    // An interior tile with a successor and a plain bf16 output stores each quadrant right after its last MFMA phase,
-    // between the phases of the last K-tile, instead of after the loop (see storeQ)
+    // An interior tile with a successor and a plain bf16 output stores its upper half (mh = 0, final after P2 of the last
+    // K-tile) under the MFMAs of P3 / P4 instead of after the loop (see the header)
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const bool early = overlap && p.Cb && !p.C && !p.pe && !p.Res && tile + G < ntiles && tm * 256 + 256 <= p.M &&
                        tn * 256 + 256 <= p.N;
-    // quadrant (mh, nh) = accumulators [mh*4 .. mh*4+3][nh*2, nh*2+1]: 4 store instructions of 16 rows x 32 bf16 per wave
-    auto storeQ = [&](int mh, int nh) {
+    // n 16-row blocks of the half mh, both column halves of each: the wave's whole 128-byte line of a row leaves in two
+    // back-to-back instructions (storing the column halves in different phases cost 13 % more HBM write bytes by PMC)
+    auto storeRows = [&](int mh, int i0, int n) {
       int er = r, eq = q4;
       asm volatile("" : "+v"(er), "+v"(eq));
-      const int j = nh * 2;
-      unsigned short* cb = p.Cb + (size_t)(tm * 256 + wr * 128 + mh * 64 + er) * p.ldcb + tn * 256 + wc * 64 + 16 * (j + (eq & 1)) + 8 * (eq >> 1);
+      unsigned short* cb = p.Cb + (size_t)(tm * 256 + wr * 128 + mh * 64 + er) * p.ldcb + tn * 256 + wc * 64 + 16 * (eq & 1) + 8 * (eq >> 1);
+      for (int i = i0; i < i0 + n; ++i) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        f32x4 a0 = acc[mh * 4 + i][j], a1 = acc[mh * 4 + i][j + 1];
-        if (p.relu) {
+        for (int j = 0; j < 4; j += 2) {
+          f32x4 a0 = acc[mh * 4 + i][j], a1 = acc[mh * 4 + i][j + 1];
+          if (p.relu) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            a0[e] = a0[e] > 0.f ? a0[e] : 0.f;
-            a1[e] = a1[e] > 0.f ? a1[e] : 0.f;
+            for (int e = 0; e < 4; ++e) {
+              a0[e] = a0[e] > 0.f ? a0[e] : 0.f;
+              a1[e] = a1[e] > 0.f ? a1[e] : 0.f;
+            }
           }
+          const auto s0 = __builtin_amdgcn_permlane16_swap(pack_bf16(a0[0], a0[1]), pack_bf16(a1[0], a1[1]), false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(pack_bf16(a0[2], a0[3]), pack_bf16(a1[2], a1[3]), false, false);
+          const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+          *reinterpret_cast<u32x4*>(cb + (size_t)i * 16 * p.ldcb + 16 * j) = v;
         }
-        const auto s0 = __builtin_amdgcn_permlane16_swap(pack_bf16(a0[0], a0[1]), pack_bf16(a1[0], a1[1]), false, false);
-        const auto s1 = __builtin_amdgcn_permlane16_swap(pack_bf16(a0[2], a0[3]), pack_bf16(a1[2], a1[3]), false, false);
-        const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
-        *reinterpret_cast<u32x4*>(cb + (size_t)i * 16 * p.ldcb) = v;
       }
     };
 
@@ -196,7 +201,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
         if (t > 0) {
           if (draining) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           else if (fl && stores == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-          else if (fl && stores == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         }
       };
@@ -221,21 +225,20 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
       mma(0, 0);
       // P2
       readB(1); issue(1); wait(0);
-      if (fl) storeQ(0, 0);
       mma(0, 1);
       // P3
-      readA(1); issue(0); wait(4);
-      if (fl) storeQ(0, 1);
+      readA(1); issue(0); wait(0);
+      if (fl) storeRows(0, 0, 2);
       mma(1, 1);
       // P4
-      issue(2); wait(8);
-      if (fl) storeQ(1, 1);
+      issue(2); wait(4);
+      if (fl) storeRows(0, 2, 2);
       mma(1, 0);
     }
     if (early) {
       // the next tile's first K-tile issues no waits: its last half-tile (h1, issued in P2) must have landed.  Younger
-      // than it: 4 x 4 stores and the two half-tiles of P3 / P4 = 20 instructions
-      storeQ(1, 0);
+      // than it: 16 stores and the two half-tiles of P3 / P4 = 20 instructions
+      storeRows(1, 0, 4);
       asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
       continue;
     }

@@ -148,7 +148,7 @@ enum Option {
   OPT_ROW_TILE,            // 0 (default): row kernel picks its tile height; 2 | 4 | 8 | 10 forces 16 x that many rows
   OPT_ATTN_TRAIN_ROWWISE,  // 1: training attention on the row-wise kernels whatever the shape (default 0)
   OPT_CONV8,               // 1 (default): conv stacks of the bf16 mode on the phase-pipelined LDS-DMA kernel where it applies
-  OPT_STORE_OVERLAP,       // 1 (default): the 256 x 256 GEMM stores a tile's quadrants between the phases of its last K-tile
+  OPT_STORE_OVERLAP,       // 1 (default): the 256 x 256 GEMM stores a tile's upper half between the phases of its last K-tile
   OPT_COUNT
 };
 int option(Option o);

@@ -190,7 +190,7 @@ def test_persistent_ln_epilogues_match_reference_and_repeat(M, K):
                 torch.equal(xr, first[3]), f"run {rep} differs"
 
 
-# ---- bf16-only output of interior tiles with a successor: the quadrants are stored between the phases of the last
+# ---- bf16-only output of interior tiles with a successor: the tile's upper half is stored between the phases of the last
 # K-tile (store_overlap).  Same accumulators, same rounding: the result equals the stores-after-the-loop path bit for bit.
 @pytest.mark.parametrize("M,N,K,relu", [(75776, 2048, 512, 1), (75776, 1536, 512, 0), (40000, 1024, 128, 1),
                                         (30001, 1536, 2048, 0), (66000, 376, 512, 0)])
