@@ -186,7 +186,9 @@ int pt_attention_bf16(const void* Q, int ldq, const void* K, int ldk, const void
                       int Nq, int Nk, int H, void* stream);
 /* measurement aid (bench.py roofline leg): when enabled every tap-GEMM launch is bracketed by HIP events
  * on its stream; pt_prof_read sums elapsed ms / algorithmic FLOPs / launches per kernel config
- * {fp32 128x128, 64x128, 64x64, bf16 128x128, 64x128, 64x64, bf16 256x256, bf16 128x512} (arrays of 8);
+ * {0-2: fp32 tap-GEMM 128x128 / 64x128 / 64x64 tiles, 3-5: 4-wave bf16 tap-GEMM 128x128 / 64x128 / 64x64 and the conv
+ * stacks' 256x256 LDS-DMA kernel, 6: bf16 256x256 Linears (gemm8), 7: bf16 N = 512 row-complete Linears with their
+ * LayerNorm epilogues (row kernels, fused sub-layer tail)} (arrays of 8);
  * call it after synchronising. */
 int pt_prof_enable(int on);
 int pt_prof_read(double* ms8, double* flops8, int* launches8);
@@ -307,6 +309,11 @@ int pt_postprocess_poses(const float* pred, int B, int T, const float* mean, con
  *   "conv8"              1 (default) conv stacks of the bf16 mode on the phase-pipelined LDS-DMA tap-GEMM where it applies
  *   "store_overlap"      1 (default) the 256 x 256 GEMM stores a bf16 tile's upper half between the phases of its last
  *                        K-tile; 0 = after the loop (same bits either way)
+ *   "row2"               1 = N = 512 Linears with at least row2_min_rows rows run as 80-row tiles, two workgroups per CU
+ *                        (gemm_bf16_row2.hip: LayerNorm epilogues beside the other workgroup's MFMAs); default 0 = the
+ *                        one-workgroup-per-CU row kernel everywhere (bit-identical results; the two-workgroup form
+ *                        measured 8-30 % slower per launch)
+ *   "row2_min_rows"      rows from which row2 applies (default 20480 = 80 rows x 256 CUs)
  * Unknown names and out-of-range values are errors (non-zero return, pt_last_error). */
 int pt_set_option(const char* name, int value);
 int pt_get_option(const char* name, int* value);

@@ -1,6 +1,7 @@
 // extern "C" surface of libprobtalk_hip.so (declarations: include/probtalk_hip.h).
 #include <cstring>
 #include <mutex>
+#include <string>
 
 #include "../../include/probtalk_hip.h"
 #include "model.h"
@@ -73,13 +74,26 @@ int scratch_for_current_device(void** out) {
 }
 
 // ---- run-time options (pt_common.h: Option).  Plain ints: set them before the calls they affect, from one thread.
-int g_opt[pt::OPT_COUNT] = {1, -1, 2048, 0, 0, 1, 1};
-const char* const g_opt_name[pt::OPT_COUNT] = {"resid_bf16", "fused_tail", "small_rows", "row_tile", "attn_train_rowwise", "conv8", "store_overlap"};
+// One table: name, default, allowed range (row_tile additionally takes only the built tile heights).
+struct OptSpec { const char* name; int def, lo, hi; };
+constexpr OptSpec g_opt_spec[pt::OPT_COUNT] = {
+    {"resid_bf16", 1, 0, 1},          {"fused_tail", -1, -1, 1}, {"small_rows", 2048, 0, 1 << 30},
+    {"row_tile", 0, 0, 10},           {"attn_train_rowwise", 0, 0, 1}, {"conv8", 1, 0, 1},
+    {"store_overlap", 1, 0, 1},       {"row2", 0, 0, 1},         {"row2_min_rows", 20480, 0, 1 << 30},
+};
+int g_opt[pt::OPT_COUNT] = {g_opt_spec[0].def, g_opt_spec[1].def, g_opt_spec[2].def, g_opt_spec[3].def, g_opt_spec[4].def,
+                            g_opt_spec[5].def, g_opt_spec[6].def, g_opt_spec[7].def, g_opt_spec[8].def};
+static_assert(pt::OPT_COUNT == 9, "option table out of step with pt_common.h");
 int find_option(const char* name) {
   if (name)
     for (int i = 0; i < pt::OPT_COUNT; ++i)
-      if (strcmp(name, g_opt_name[i]) == 0) return i;
+      if (strcmp(name, g_opt_spec[i].name) == 0) return i;
   return -1;
+}
+std::string option_names() {
+  std::string all;
+  for (int i = 0; i < pt::OPT_COUNT; ++i) all += std::string(i ? ", " : "") + g_opt_spec[i].name;
+  return all;
 }
 }  // namespace
 
@@ -94,10 +108,10 @@ int pt_version(void) { return 100; }
 
 int pt_set_option(const char* name, int value) {
   const int i = find_option(name);
-  PT_CHECK(i >= 0, "pt_set_option: unknown option '%s' (resid_bf16, fused_tail, small_rows, row_tile, attn_train_rowwise, conv8)", name ? name : "(null)");
+  PT_CHECK(i >= 0, "pt_set_option: unknown option '%s' (options: %s)", name ? name : "(null)", option_names().c_str());
+  PT_CHECK(value >= g_opt_spec[i].lo && value <= g_opt_spec[i].hi, "pt_set_option: %s = %d is outside [%d, %d]", name, value,
+           g_opt_spec[i].lo, g_opt_spec[i].hi);
   PT_CHECK(i != OPT_ROW_TILE || value == 0 || value == 2 || value == 4 || value == 8 || value == 10, "pt_set_option: row_tile = 0, 2, 4, 8 or 10");
-  PT_CHECK(i != OPT_FUSED_TAIL || (value >= -1 && value <= 1), "pt_set_option: fused_tail = -1 (auto), 0 or 1");
-  PT_CHECK(i != OPT_SMALL_ROWS || value >= 0, "pt_set_option: small_rows >= 0");
   g_opt[i] = value;
   return 0;
 }

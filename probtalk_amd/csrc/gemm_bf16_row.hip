@@ -352,6 +352,9 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
         if (eq == 0) red[wave * 160 + i * 16 + er] = s;
         PT_PIN_BLOCK(i);
       }
+      // the partial sums must be IN the LDS before another wave reads them: a bare s_barrier does not wait for this
+      // wave's outstanding ds_write
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       // the 8 per-wave partials of a row: each of the row's 4 lanes reads two of them (one ds_read2), the lane sum does
       // the rest.  All MT blocks' reads go out in one batch (independent, one wait) instead of one dependent LDS round
@@ -377,8 +380,8 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
         if (eq == 0) red[8 * 160 + wave * 160 + i * 16 + er] = s;
         PT_PIN_BLOCK(i);
       }
-      // every K-tile staged so far has landed before the stores join the in-order vmcnt queue
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // every K-tile staged so far has landed before the stores join the in-order vmcnt queue (and the sums are in the LDS)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
@@ -447,6 +450,8 @@ static int launch_row(const GemmBigArgs& a, hipStream_t s) {
   return 0;
 }
 
+int launch_gemm_row2(const GemmBigArgs& a, hipStream_t s);
+
 // Tile height: the one whose tile count wastes less of the last round of the persistent grid.
 int launch_gemm_row(const GemmBigArgs& a, hipStream_t s) {
   if (gr_num_cus == 0) {
@@ -456,6 +461,9 @@ int launch_gemm_row(const GemmBigArgs& a, hipStream_t s) {
     gr_num_cus = n > 0 ? n : 256;
   }
   const int force_mt = option(OPT_ROW_TILE);
+  // enough rows for more 80-row tiles than CUs: two workgroups per CU, epilogues beside the other workgroup's MFMAs
+  if (!force_mt && option(OPT_ROW2) == 1 && a.M >= option(OPT_ROW2_MIN_ROWS) && (a.epi != EPI_LNMOD || a.n_classes <= GR_TAB_CLASSES))
+    return launch_gemm_row2(a, s);
   auto cost = [&](int bm) {
     const long tiles = (a.M + bm - 1) / bm;
     return ((tiles + gr_num_cus - 1) / gr_num_cus) * (long)bm;

@@ -149,6 +149,8 @@ enum Option {
   OPT_ATTN_TRAIN_ROWWISE,  // 1: training attention on the row-wise kernels whatever the shape (default 0)
   OPT_CONV8,               // 1 (default): conv stacks of the bf16 mode on the phase-pipelined LDS-DMA kernel where it applies
   OPT_STORE_OVERLAP,       // 1 (default): the 256 x 256 GEMM stores a tile's upper half between the phases of its last K-tile
+  OPT_ROW2,                // 1: N = 512 Linears with at least row2_min_rows rows run two 80-row workgroups per CU (gemm_bf16_row2.hip); default 0 (measured slower)
+  OPT_ROW2_MIN_ROWS,       // rows from which the two-workgroups-per-CU row kernel is used (default 20480 = 80 rows x 256 CUs)
   OPT_COUNT
 };
 int option(Option o);

@@ -217,3 +217,49 @@ def test_early_quadrant_stores_equal_late_stores(M, N, K, relu):
     assert float((outs[0][:, :N].double() - ref).abs().max()) / scale < 5e-3
     assert bool((outs[0][:, N:] == 7.0).all())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+# ---- option row2 = 1: N = 512 Linears from 20,480 rows on run as 80-row tiles, two workgroups per CU
+# (gemm_bf16_row2.hip).  Same K order, same accumulator layout, same epilogue arithmetic as the one-workgroup-per-CU row
+# kernel: bit-identical results.  (Its first version exposed a race both kernels shared: the LayerNorm partial sums were
+# written to LDS with no lgkmcnt wait in front of the bare s_barrier.)
+@pytest.mark.parametrize("M,K", [(40003, 512), (37888, 2048), (20480, 64)])
+def test_two_workgroups_per_cu_row_kernel_equals_persistent_row_kernel(M, K):
+    L = _lib.lib()
+    A, W, bias, Np = _mk(M, 512, K, 41)
+    g = torch.Generator().manual_seed(8)
+    gamma, beta = 1 + 0.3 * torch.randn(512, generator=g), 0.2 * torch.randn(512, generator=g)
+    style = 0.5 * torch.randn(3, 1024, generator=g)
+    rpc = 148
+    nclip = (M + rpc - 1) // rpc
+    label = torch.randint(0, 3, (nclip,), generator=g)
+    x0 = torch.randn(M, 512, generator=g)
+    fold = torch.cat([gamma * (1 + style[:, :512]), beta * (1 + style[:, :512]) + style[:, 512:]], dim=1).contiguous()
+    Ad, Wd, bd, sd, ld, gd, btd, x0d = (t.cuda() for t in (A, W, bias, fold, label, gamma, beta, x0))
+    res = []
+    try:
+        for mode in (1, 0):
+            _lib.check(L.pt_set_option(b"row2", mode))
+            C = torch.full((M, 520), 7.0, device="cuda")
+            Cb = torch.full((M, 520), 7.0, device="cuda", dtype=torch.bfloat16)
+            _lib.check(L.pt_gemm_bf16(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, 512, K, Np, _lib.ptr(C), 520, _lib.ptr(Cb), 520, 1,
+                                      _lib.stream()))
+            out = torch.empty(M, 512, device="cuda", dtype=torch.bfloat16)
+            _lib.check(L.pt_gemm_bf16_lnmod(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, K, Np, _lib.ptr(sd), _lib.ptr(ld), nclip, rpc, 3,
+                                            _lib.ptr(out), _lib.stream()))
+            xd = x0d.clone()
+            xb = torch.empty(M, 512, device="cuda", dtype=torch.bfloat16)
+            _lib.check(L.pt_gemm_bf16_addln(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, K, Np, _lib.ptr(gd), _lib.ptr(btd), _lib.ptr(xd),
+                                            _lib.ptr(xb), _lib.stream()))
+            xr = x0d.bfloat16()
+            _lib.check(L.pt_gemm_bf16_addln(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, K, Np, _lib.ptr(gd), _lib.ptr(btd), None,
+                                            _lib.ptr(xr), _lib.stream()))
+            torch.cuda.synchronize()
+            res.append((C, Cb, out, xd, xb, xr))
+    finally:
+        _lib.check(L.pt_set_option(b"row2", 0))
+    ref = (Ad.double() @ Wd[:512].double().t() + bd[:512].double()).clamp_min(0)
+    assert float((res[0][0][:, :512].double() - ref).abs().max()) / float(ref.abs().max()) < 2e-6
+    assert bool((res[0][0][:, 512:] == 7.0).all()) and bool((res[0][1][:, 512:] == 7.0).all())
+    for name, a, b in zip(("fp32", "bf16", "lnmod", "addln x", "addln xb", "addln bf16 stream"), res[0], res[1]):
+        assert torch.equal(a, b), f"{name}: two-workgroup kernel differs from the persistent row kernel"
