@@ -134,7 +134,9 @@ int pt_conv1d_cl(const float* A, int lda, const float* Wpacked, const float* bia
                  int B, int Lin, float* C, int ldc, int act, float slope, const float* Res, int ldr, void* stream);
 /* The same conv on bf16 operands (bf16 mode of the conv stacks): A [B*Lin, lda] bf16 channels-last, Wpacked
  * [taps][Npad][K] bf16 (K % 64 == 0), fp32 accumulation; output fp32 rows (C) and/or bf16 rows (Cb); optional bf16
- * residual indexed by output row.  Large shapes run on the phase-pipelined LDS-DMA tap-GEMM (option "conv8"). */
+ * residual indexed by output row.  Large shapes run on the phase-pipelined LDS-DMA tap-GEMM (option "conv8").
+ * The FIRST call on a device allocates a 256-byte zero block (kept until the process ends) unless a bf16 model has been
+ * finalized on that device before: do not make that first call under stream capture. */
 int pt_conv1d_cl_bf16(const void* A, int lda, const void* Wpacked, const float* bias, int N, int Npad, int K, int kind, int B,
                       int Lin, float* C, int ldc, void* Cb, int ldcb, int act, float slope, const void* ResB, int ldr,
                       void* stream);

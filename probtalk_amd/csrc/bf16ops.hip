@@ -375,26 +375,15 @@ int launch_attention_bf16(const unsigned short* Q, int ldq, const unsigned short
   const size_t smem = (size_t)Nkp * 256 + (size_t)nw * 32 * 144;
   if (smem > 160 * 1024) {
     // beyond the LDS-resident limit (544 keys with 10 waves): K / V stream through LDS in chunks
-    static bool sattr = false;
-    if (!sattr) {
-      PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bf16_stream_kernel<CT>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      sattr = true;
-    }
+    PT_ENSURE_LDS((attention_bf16_stream_kernel<CT>), 160 * 1024);
     const int snw = qtiles < 10 ? qtiles : 10;
     const size_t ssmem = (size_t)AS_KC * 256 + (size_t)snw * 32 * 144;
     PT_LAUNCH((attention_bf16_stream_kernel<CT>), dim3(B * H, (qtiles + snw - 1) / snw), dim3(64 * snw), ssmem, s, Q, ldq, K, ldk,
               V, ldv, O, ldo, Nq, Nk, H, qtiles, 0.125f * 1.4426950408889634f);
     return 0;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bf16_kernel<CT, 320, 4>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bf16_kernel<CT, 640, 3>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  PT_ENSURE_LDS((attention_bf16_kernel<CT, 320, 4>), 160 * 1024);
+  PT_ENSURE_LDS((attention_bf16_kernel<CT, 640, 3>), 160 * 1024);
   // up to 5 query tiles: 5-wave workgroups, 128 registers (two workgroups per CU at 148 keys); longer sequences:
   // up to 10 waves sharing one K/V image, 168 registers
   if (nw <= 5)

@@ -11,6 +11,7 @@ using namespace pt;
 
 struct pt_model {
   Model m;
+  void* scratch = nullptr;   // vqvae kinds: this device's copy of the static scratch array, resolved at pt_model_create
 };
 
 namespace pt {
@@ -135,11 +136,12 @@ pt_model* pt_model_create(const char* kind, const int* cfg, int ncfg) {
     set_error("pt_model_create: no HIP device available");
     return nullptr;
   }
+  void* scratch_ptr = nullptr;
   if (strncmp(kind, "vqvae", 5) == 0) {   // set-up time: resolve this device's static scratch (pt_pq_quantize_static)
-    void* p = nullptr;
-    if (scratch_for_current_device(&p)) return nullptr;
+    if (scratch_for_current_device(&scratch_ptr)) return nullptr;
   }
   pt_model* h = new pt_model();
+  h->scratch = scratch_ptr;
   h->m.kind = kind;
   h->m.cfg.assign(cfg, cfg + ncfg);
   return h;
@@ -172,7 +174,11 @@ int pt_model_set_precision(pt_model* h, int precision) {
 
 int pt_model_finalize(pt_model* h) {
   PT_CHECK(h, "pt_model_finalize: null model");
-  return finalize_model(h->m);
+  if (finalize_model(h->m)) return 1;
+  // set-up time, current device: the code search's dynamic-LDS attribute, so that pt_pq_quantize_static itself makes no
+  // runtime query (it may run under stream capture)
+  if (h->scratch && pq_search_prepare(h->m.vq.emb_dim / h->m.vq.groups)) return 1;
+  return 0;
 }
 
 void pt_model_destroy(pt_model* h) { delete h; }
@@ -224,15 +230,17 @@ int pt_pq_quantize_static(pt_model* h, const float* z, int B, int W, float* quan
   PT_CHECK(rows <= PT_PQ_STATIC_MAX_ROWS && ld <= PT_PQ_STATIC_MAX_LD,
            "pt_pq_quantize_static: %lld latent rows of %d floats exceed the static scratch (at most %d rows of %d floats); "
            "use pt_pq_quantize with a caller workspace", rows, ld, PT_PQ_STATIC_MAX_ROWS, PT_PQ_STATIC_MAX_LD);
-  void* base = nullptr;
-  if (scratch_for_current_device(&base)) return 1;
+  // the address was resolved for the device the model was created on (pt_model_create), where it has to be used: no
+  // lock and no runtime query here
+  void* base = h->scratch;
+  PT_CHECK(base != nullptr, "pt_pq_quantize_static: the model holds no static scratch address");
   hipStream_t s = (hipStream_t)stream;
   // both images are written in full (all ld columns of every row) before they are read: nothing has to start at zero
   float* z_cl = (float*)base;
   float* q_cl = z_cl + (size_t)PT_PQ_STATIC_MAX_ROWS * PT_PQ_STATIC_MAX_LD;
   if (launch_ncl_to_cl(z, z_cl, B, v.emb_dim, W, ld, 0, ld, s)) return 1;
   if (launch_pq_search(z_cl, ld, v.codebooks, B * W, v.groups, v.emb_dim / v.groups, v.num_codes, indices,
-                       quantized ? q_cl : nullptr, ld, s)) return 1;
+                       quantized ? q_cl : nullptr, ld, s, true)) return 1;
   if (quantized && launch_cl_to_ncl(q_cl, ld, 0, quantized, B, v.emb_dim, W, s)) return 1;
   return 0;
 }

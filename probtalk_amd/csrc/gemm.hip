@@ -231,12 +231,7 @@ template <int MI, int NI>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
   constexpr int BM = 64 * MI, BN = 64 * NI;
   constexpr size_t smem = 2 * (size_t)(BM + BN) * LDS_ST * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<MI, NI>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
-  }
+  PT_ENSURE_LDS((gemm_f32_kernel<MI, NI>), smem);
   const int tiles_m = (a.M + BM - 1) / BM;
   const int tiles_n = (a.N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;

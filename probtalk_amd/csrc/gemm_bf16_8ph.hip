@@ -307,20 +307,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
   if (wr == 0) __builtin_amdgcn_s_barrier();                    // balances the extra barrier waves 4-7 took in the prologue
 }
 
-static int g8_num_cus = 0;
-
 int launch_gemm8(const GemmBigArgs& a, int cfg, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G8_SMEM));
-    attr_set = true;
-  }
-  if (g8_num_cus == 0) {
-    int dev = 0, n = 0;
-    PT_HIP(hipGetDevice(&dev));
-    PT_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-    g8_num_cus = n > 0 ? n : 256;
-  }
+  PT_ENSURE_LDS(gemm8_kernel, G8_SMEM);
+  const int g8_num_cus = device_cus();
   const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256, ntiles = tiles_m * tiles_n;
   const int grid = ntiles < g8_num_cus ? ntiles : g8_num_cus;
   void* tok = nullptr;

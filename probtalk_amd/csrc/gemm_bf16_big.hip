@@ -357,23 +357,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_big_kernel(const GemmBigArg
   }
 }
 
-static int g_num_cus = 0;
 // WPC workgroups per CU are resident (LDS / register budget of the configuration); the persistent grid is WPC x #CUs.
 template <int BM, int BN, int WM, int WN, int BK, int EPI, int WPC>
 static int launch_big(const GemmBigArgs& a, int cfg, hipStream_t s) {
   constexpr size_t smem = 2 * (size_t)(BM + BN) * BK * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<BM, BN, WM, WN, BK, EPI>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
-  }
-  if (g_num_cus == 0) {
-    int dev = 0, n = 0;
-    PT_HIP(hipGetDevice(&dev));
-    PT_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-    g_num_cus = n > 0 ? n : 256;
-  }
+  PT_ENSURE_LDS((gemm_big_kernel<BM, BN, WM, WN, BK, EPI>), smem);
+  const int g_num_cus = device_cus();
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
   const int slots = WPC * g_num_cus;
   const int grid = ntiles < slots ? ntiles : slots;      // persistent: resident workgroups loop over the tiles

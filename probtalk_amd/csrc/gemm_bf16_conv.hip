@@ -12,6 +12,8 @@
 // Replaces the 4-wave register-staged gemm_bf16_kernel for these shapes (measured there: 280 TFLOP/s, 2-byte stores).
 #include <cstdlib>
 
+#include <mutex>
+
 #include "pt_common.h"
 
 namespace pt {
@@ -334,17 +336,23 @@ __global__ __launch_bounds__(512) void conv8_kernel(const GemmArgsB p, const uns
 
 // ---- the zero block invalid frames read (one per device, allocated at model finalize time, never freed)
 static unsigned char* c8_zero[64] = {};
-static int c8_num_cus = 0;
 
+// First use on a device allocates 256 bytes and fills them synchronously: under a lock (two threads may make first
+// calls), and at model finalize time for the model path, so that no launch allocates.  The op-level entry point
+// pt_conv1d_cl_bf16 calls it too: its FIRST call per device may therefore allocate (documented in the header) and must
+// not be made under stream capture.
+static std::mutex c8_mu;
 int conv8_prepare() {
   int dev = 0;
   PT_HIP(hipGetDevice(&dev));
   PT_CHECK(dev >= 0 && dev < 64, "conv8: device ordinal %d out of range", dev);
+  if (__atomic_load_n(&c8_zero[dev], __ATOMIC_ACQUIRE)) return 0;
+  std::lock_guard<std::mutex> lk(c8_mu);
   if (!c8_zero[dev]) {
     void* z = nullptr;
     PT_HIP(hipMalloc(&z, 256));
     PT_HIP(hipMemset(z, 0, 256));
-    c8_zero[dev] = (unsigned char*)z;
+    __atomic_store_n(&c8_zero[dev], (unsigned char*)z, __ATOMIC_RELEASE);
   }
   return 0;
 }
@@ -368,16 +376,8 @@ int launch_conv8(const GemmArgsB& a, hipStream_t s) {
   int dev = 0;
   PT_HIP(hipGetDevice(&dev));
   PT_CHECK(conv8_takes(a), "conv8: shape not supported (internal dispatch error)");
-  static bool attr_set = false;
-  if (!attr_set) {
-    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C8_SMEM));
-    attr_set = true;
-  }
-  if (c8_num_cus == 0) {
-    int n = 0;
-    PT_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-    c8_num_cus = n > 0 ? n : 256;
-  }
+  PT_ENSURE_LDS(conv8_kernel, C8_SMEM);
+  const int c8_num_cus = device_cus();
   const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256, ntiles = tiles_m * tiles_n;
   const int grid = ntiles < c8_num_cus ? ntiles : c8_num_cus;
   void* tok = nullptr;

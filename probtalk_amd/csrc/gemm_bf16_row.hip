@@ -432,15 +432,11 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
   if (grp == 0) __builtin_amdgcn_s_barrier();                    // balances the extra barrier waves 4-7 took in the prologue
 }
 
-static int gr_num_cus = 0;
 
 template <int MT, int EPI>
 static int launch_row(const GemmBigArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_row_kernel<MT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, GR_SMEM));
-    attr_set = true;
-  }
+  PT_ENSURE_LDS((gemm_row_kernel<MT, EPI>), GR_SMEM);
+  const int gr_num_cus = device_cus();
   const int ntiles = (a.M + 16 * MT - 1) / (16 * MT);
   const int grid = ntiles < gr_num_cus ? ntiles : gr_num_cus;
   void* tok = nullptr;
@@ -454,12 +450,7 @@ int launch_gemm_row2(const GemmBigArgs& a, hipStream_t s);
 
 // Tile height: the one whose tile count wastes less of the last round of the persistent grid.
 int launch_gemm_row(const GemmBigArgs& a, hipStream_t s) {
-  if (gr_num_cus == 0) {
-    int dev = 0, n = 0;
-    PT_HIP(hipGetDevice(&dev));
-    PT_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-    gr_num_cus = n > 0 ? n : 256;
-  }
+  const int gr_num_cus = device_cus();
   const int force_mt = option(OPT_ROW_TILE);
   // enough rows for more 80-row tiles than CUs: two workgroups per CU, epilogues beside the other workgroup's MFMAs
   if (!force_mt && option(OPT_ROW2) == 1 && a.M >= option(OPT_ROW2_MIN_ROWS) && (a.epi != EPI_LNMOD || a.n_classes <= GR_TAB_CLASSES))

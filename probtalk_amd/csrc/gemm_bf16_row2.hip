@@ -354,18 +354,9 @@ __global__ __launch_bounds__(512, 4) void gemm_row2_kernel(const GemmBigArgs p) 
 #undef PT_PIN_BLOCK2
 }
 
-constexpr int R2_MAXDEV = 64;
-
 template <int MT, int EPI>
 static int launch_row2_t(const GemmBigArgs& a, hipStream_t s) {
-  static bool attr_set[R2_MAXDEV] = {};
-  int dev = 0;
-  PT_HIP(hipGetDevice(&dev));
-  PT_CHECK(dev >= 0 && dev < R2_MAXDEV, "gemm_row2: device ordinal %d out of range", dev);
-  if (!attr_set[dev]) {
-    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_row2_kernel<MT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, r2_smem(MT)));
-    attr_set[dev] = true;
-  }
+  PT_ENSURE_LDS((gemm_row2_kernel<MT, EPI>), r2_smem(MT));
   const int ntiles = (a.M + 16 * MT - 1) / (16 * MT);
   void* tok = nullptr;
   if (prof_is_on()) prof_record_begin(s, a.flops > 0 ? a.flops : 2.0 * a.M * a.N * a.K, 7, &tok);

@@ -314,20 +314,23 @@ __global__ __launch_bounds__(256) void sublayer_kernel(const SubArgs p, const in
         // one pass over the accumulators for both moments (every v_accvgpr_read is a VALU slot of a lone wave)
         float mean, rstd;
         {
+          // two passes (mean, then squared deviations), as the two-launch path's row kernel and nn.LayerNorm do: the
+          // one-pass E[x^2] - mean^2 loses the variance of rows whose mean is large against their spread, and which
+          // of the two paths a tail takes depends on the batch size
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
           for (int nb = 0; nb < 32; ++nb)
 #pragma unroll
+            for (int e = 0; e < 4; ++e) s1 += acc[mb][nb][e];
+          mean = row_lanes_sum(s1) * (1.f / 512.f);
+#pragma unroll
+          for (int nb = 0; nb < 32; ++nb)
+#pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float v = acc[mb][nb][e];
-              s1 += v;
-              s2 = __builtin_fmaf(v, v, s2);
+              const float d = acc[mb][nb][e] - mean;
+              s2 = __builtin_fmaf(d, d, s2);
             }
-          s1 = row_lanes_sum(s1);
-          s2 = row_lanes_sum(s2);
-          mean = s1 * (1.f / 512.f);
-          const float var = __builtin_fmaf(-mean, mean, s2 * (1.f / 512.f));
-          rstd = __builtin_amdgcn_rsqf((var > 0.f ? var : 0.f) + 1e-5f);
+          rstd = __builtin_amdgcn_rsqf(row_lanes_sum(s2) * (1.f / 512.f) + 1e-5f);
         }
         SB_PIN_MB(mb);
         const float nmr = -mean * rstd;
@@ -464,8 +467,6 @@ int launch_permute_k32(const unsigned short* in, unsigned short* out, int N, int
   return 0;
 }
 
-static int sb_num_cus = 0;
-
 int launch_sublayer(const SubArgs& a, hipStream_t s) {
   PT_CHECK(a.M > 0 && a.A && a.W1 && a.b1 && a.fold && a.label && a.W2p && a.b2 && a.gamma && a.beta && a.X, "sublayer: null argument");
   PT_CHECK(a.K1 >= 64 && a.K1 % 32 == 0 && a.lda >= a.K1 && a.lda % 8 == 0, "sublayer: K1=%d (multiple of 32, >= 64) lda=%d", a.K1, a.lda);
@@ -475,18 +476,8 @@ int launch_sublayer(const SubArgs& a, hipStream_t s) {
   PT_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W1 & 15) == 0 && ((uintptr_t)a.W2p & 15) == 0 && ((uintptr_t)a.X & 15) == 0,
            "sublayer: operands must be 16-byte aligned");
   PT_CHECK((double)a.M * a.lda * 2 < 2.0e9, "sublayer: A larger than 2 GB (32-bit buffer offsets)");
-  if (sb_num_cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    PT_HIP(hipGetDevice(&dev));
-    PT_HIP(hipGetDeviceProperties(&prop, dev));
-    sb_num_cus = prop.multiProcessorCount;
-  }
-  static bool attr_set = false;
-  if (!attr_set) {
-    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sublayer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SB_SMEM));
-    attr_set = true;
-  }
+  const int sb_num_cus = device_cus();
+  PT_ENSURE_LDS(sublayer_kernel, SB_SMEM);
   const int ntiles = (a.M + 127) / 128;
   const int grid = ntiles < sb_num_cus ? ntiles : sb_num_cus;
   void* tok = nullptr;
@@ -498,13 +489,7 @@ int launch_sublayer(const SubArgs& a, hipStream_t s) {
 
 // Workgroups the persistent grid runs with on this device (the dispatch in transformer.hip prices whole rounds of it).
 int sublayer_grid_limit() {
-  if (sb_num_cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-    sb_num_cus = prop.multiProcessorCount;
-  }
-  return sb_num_cus;
+  return device_cus();
 }
 
 }  // namespace pt

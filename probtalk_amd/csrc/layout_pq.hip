@@ -202,19 +202,22 @@ __global__ __launch_bounds__(256) void pq_search_kernel(const float* __restrict_
   }
 }
 
+static size_t pq_search_smem(int D) { return ((size_t)(PQ_ROWS + PQ_CODES) * (D + 4) + PQ_ROWS + PQ_CODES + 5 * PQ_ROWS) * sizeof(float); }
+static LdsAttr pq_lds_attr;
+
+int pq_search_prepare(int D) {
+  PT_CHECK(D % 8 == 0 && D >= 8 && D <= 256, "pq_search: code dim %d must be a multiple of 8 in [8,256]", D);
+  return ensure_dyn_lds(reinterpret_cast<const void*>(pq_search_kernel), (int)pq_search_smem(D), pq_lds_attr);
+}
+
 int launch_pq_search(const float* z_cl, int ldz, const float* codebooks, int rows, int G, int D, int K, int64_t* idx,
-                     float* q_cl, int ldq, hipStream_t s) {
+                     float* q_cl, int ldq, hipStream_t s, bool prepared) {
   PT_CHECK(rows > 0 && G > 0 && K > 0, "pq_search: empty problem rows=%d G=%d K=%d", rows, G, K);
   PT_CHECK(D % 8 == 0 && D >= 8 && D <= 256, "pq_search: code dim %d must be a multiple of 8 in [8,256]", D);
   PT_CHECK(ldz >= G * D && ldz % 4 == 0 && (q_cl == nullptr || (ldq >= G * D && ldq % 4 == 0)),
            "pq_search: leading dims ldz=%d ldq=%d too small for G*D=%d", ldz, ldq, G * D);
-  const size_t smem = ((size_t)(PQ_ROWS + PQ_CODES) * (D + 4) + PQ_ROWS + PQ_CODES + 5 * PQ_ROWS) * sizeof(float);
-  static size_t attr = 0;
-  if (smem > attr) {
-    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pq_search_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr = smem;
-  }
+  const size_t smem = pq_search_smem(D);
+  if (!prepared && ensure_dyn_lds(reinterpret_cast<const void*>(pq_search_kernel), (int)smem, pq_lds_attr)) return 1;
   dim3 grid((rows + PQ_ROWS - 1) / PQ_ROWS, G);
   PT_LAUNCH(pq_search_kernel, grid, dim3(256), smem, s, z_cl, ldz, codebooks, rows, G, D, K, idx, q_cl, ldq);
   return 0;

@@ -140,6 +140,18 @@ int launch_sublayer(const SubArgs& a, hipStream_t s);
 int sublayer_grid_limit();
 int launch_permute_k32(const unsigned short* in, unsigned short* out, int N, int K, hipStream_t s);
 
+// Per-device launch state (device.hip).  The library may be used on several GPUs from one process: the dynamic-LDS
+// attribute of a kernel and the CU count belong to the CURRENT device, so both are cached per device ordinal.
+constexpr int PT_MAX_DEVICES = 64;
+struct LdsAttr { int bytes[PT_MAX_DEVICES]; };            // zero-initialised static per kernel: largest size set so far
+int ensure_dyn_lds(const void* kernel, int bytes, LdsAttr& st);   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per device
+int device_cus();                                          // CUs of the current device (256 if the query fails)
+#define PT_ENSURE_LDS(kernel, bytes)                                                        \
+  do {                                                                                      \
+    static ::pt::LdsAttr lds_attr_;                                                         \
+    if (::pt::ensure_dyn_lds(reinterpret_cast<const void*>(kernel), (int)(bytes), lds_attr_)) return 1; \
+  } while (0)
+
 // Run-time options: the library's only switches (pt_set_option / pt_get_option); nothing reads the environment.
 enum Option {
   OPT_RESID_BF16,          // 1 (default): bf16 mode keeps the residual stream in bf16; 0: fp32 stream with a bf16 shadow
@@ -166,8 +178,10 @@ int launch_postprocess(const float* pred, int B, int T, const float* mean, const
                        const float* lower, float* out, int ld, hipStream_t s);
 
 // product quantizer
+// prepared = true: pq_search_prepare(D) has run on this device (model finalize), no attribute call here
 int launch_pq_search(const float* z_cl, int ldz, const float* codebooks, int rows, int G, int D, int K,
-                     int64_t* idx, float* q_cl, int ldq, hipStream_t s);
+                     int64_t* idx, float* q_cl, int ldq, hipStream_t s, bool prepared = false);
+int pq_search_prepare(int D);
 int launch_pq_gather(const void* idx, int idx_is_i64, const float* codebooks, int rows, int G, int D, int K,
                      float* q_cl, int ldq, int zero_to, hipStream_t s);
 

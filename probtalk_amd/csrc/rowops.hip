@@ -374,7 +374,9 @@ int launch_interp_blend(const float* pred, int B, int C, int T_in, int T_out, co
   PT_CHECK(B > 0 && C > 0 && T_in > 0 && T_out > 0, "interp_blend: empty tensor");
   PT_CHECK((gt == nullptr) == (mask == nullptr), "interp_blend: gt and mask go together");
   const size_t total = (size_t)B * C * T_out;
-  PT_CHECK(total < (1ull << 32), "interp_blend: %zu output elements (limit 2^32 per call)", total);
+  // the kernels' 32-bit grid-stride counters advance by up to 8192 * 256 per step: the limit leaves that much headroom
+  // below 2^32 so that the last increment cannot wrap
+  PT_CHECK(total <= (1ull << 32) - 8192ull * 256ull, "interp_blend: %zu output elements (limit 2^32 - 2^21 per call)", total);
   const bool aligned = ((((uintptr_t)pred | (uintptr_t)gt | (uintptr_t)mask | (uintptr_t)out) & 15) == 0);
   if ((pred == nullptr || T_in == T_out) && T_out % 4 == 0 && aligned) {
     const unsigned total4 = (unsigned)(total / 4);

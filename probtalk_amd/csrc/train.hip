@@ -780,12 +780,7 @@ int launch_attention_train_fwd(const float* Q, int ldq, const float* K, int ldk,
   PT_CHECK(Q && K && V && O && B > 0 && Nq > 0 && Nk > 0 && H > 0 && pdrop >= 0.f && pdrop < 1.f, "attention_train_fwd: bad argument");
   if (at_lds_bytes(Nq, Nk, false) <= 160 * 1024 && at_aligned(Q, ldq) && at_aligned(K, ldk) && at_aligned(V, ldv) &&
       at_aligned(O, ldo) && option(OPT_ATTN_TRAIN_ROWWISE) == 0) {
-    static bool attr = false;
-    if (!attr) {
-      PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 160 * 1024));
-      attr = true;
-    }
+    PT_ENSURE_LDS(attn_fwd_tiled_kernel, 160 * 1024);
     PT_LAUNCH(attn_fwd_tiled_kernel, dim3(B * H), dim3(AT), at_lds_bytes(Nq, Nk, false), s, Q, ldq, K, ldk, V, ldv, O, ldo, Nq,
               Nk, H, 0.125f, pdrop, seed);
     return 0;
@@ -802,12 +797,7 @@ int launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const
   if (at_lds_bytes(Nq, Nk, true) <= 160 * 1024 && Nk <= 128 && at_aligned(Q, ldq) && at_aligned(K, ldk) && at_aligned(V, ldv) &&
       at_aligned(dO, ldo) && at_aligned(dQ, lddq) && at_aligned(dK, lddk) && at_aligned(dV, lddv) &&
       option(OPT_ATTN_TRAIN_ROWWISE) == 0) {
-    static bool attr = false;
-    if (!attr) {
-      PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_tiled_kernel<2>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr = true;
-    }
+    PT_ENSURE_LDS(attn_bwd_tiled_kernel<2>, 160 * 1024);
     PT_LAUNCH(attn_bwd_tiled_kernel<2>, dim3(B * H), dim3(AT), at_lds_bytes(Nq, Nk, true), s, Q, ldq, K, ldk, V, ldv, dO, ldo, dQ,
               lddq, dK, lddk, dV, lddv, Nq, Nk, H, 0.125f, pdrop, seed);
     return 0;

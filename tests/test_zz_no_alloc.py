@@ -26,10 +26,28 @@ def _both(vq, z):
     q1 = torch.full((B, C, W), float("nan"), device="cuda")
     i1 = torch.full((B, W, G), -1, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
+    # the device's free bytes (hipMemGetInfo) see a hipMalloc made inside the library; torch.cuda.memory_allocated()
+    # only sees torch's own caching allocator.  pt_pq_quantize above was the warm-up (code object, kernel attribute).
     before = torch.cuda.memory_allocated()
+    free_before = torch.cuda.mem_get_info()[0]
     _lib.check(L.pt_pq_quantize_static(h.h, _lib.ptr(zd), B, W, _lib.ptr(q1), _lib.ptr(i1), _lib.stream()))
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.mem_get_info()[0] == free_before, "device memory was allocated inside pt_pq_quantize_static"
+    # and under stream capture, where a hipMalloc or a synchronous call would make the capture fail
+    q2 = torch.full((B, C, W), float("nan"), device="cuda")
+    i2 = torch.full((B, W, G), -1, dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        graph.capture_begin()
+        rc = L.pt_pq_quantize_static(h.h, _lib.ptr(zd), B, W, _lib.ptr(q2), _lib.ptr(i2), _lib.stream())
+        graph.capture_end()
+    assert rc == 0, L.pt_last_error()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(q2, q1) and torch.equal(i2, i1), "graph replay of pt_pq_quantize_static differs from the eager call"
     return (q0.cpu(), i0.cpu()), (q1.cpu(), i1.cpu())
 
 
