@@ -30,6 +30,12 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak (never the 2:1-sparsity figure)
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s measured achievable)
+# fp32 tap-GEMM with option split_bf16 (default): six bf16 MFMA products per fp32 multiply-add, so the roof of the
+# ALGORITHMIC fp32 FLOP rate is the dense bf16 peak / 6
+PEAK_F32_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+MFLOP_PER_FRAME_VQVAE = 15.86    # PQ-VAE encode 8.11 + quantize 0.016 + decode 7.73
+PQ_BYTES_PER_LATENT_STEP = 4128  # read z 2048 + write q 2048 + 4 int64 indices
 MFLOP_PER_FRAME = 296.0          # full pipeline, algorithmic (2*MAC of the reference modules)
 
 
@@ -63,6 +69,107 @@ def cpu_baseline(B=32, T=300, runs=5):
     return {"value": B * T / med, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"full pipeline (oracle: AudEnc+predictor 8 passes+PQ decode+refiner), {B} clips x {T} frames, "
                       f"fp32, median of {runs} runs after 1 warm-up ({med:.2f} s/run)"}
+
+
+def split_on():
+    import ctypes
+    from probtalk_amd import _lib
+    v = ctypes.c_int()
+    _lib.check(_lib.lib().pt_get_option(b"split_bf16", ctypes.byref(v)))
+    return v.value == 1
+
+
+def f32_peak():
+    """(peak TFLOP/s, kernel name) of the fp32 tap-GEMM as configured (option split_bf16)."""
+    if split_on():
+        return PEAK_F32_SPLIT_TFLOPS, ("pt::gemm_f32s_kernel (fp32 tap-GEMM on the bf16 MFMA: 3-term operand splits, 6 products; "
+                                       "peak = dense bf16 peak / 6)")
+    return PEAK_F32_MFMA_TFLOPS, "pt::gemm_f32_kernel (tap-GEMM, fp32 MFMA 32x32x2)"
+
+
+def vqvae_bench(a, rank, world, dev):
+    """BASELINE.json configs[1]: PQ-VAE encode -> nearest-code search -> decode (VQVAE_SC.forward, vqvae_1d_sc.py:300-324),
+    `--batch` (256) synthetic 88-frame clips per GPU per step, fp32, one launch sequence.  Rooflines: the fp32 tap-GEMM
+    (encoder + decoder convs, MFMA) from the per-launch HIP events, and the code search kernel against HBM: its
+    algorithmic bytes (4128 per latent step) over its own launch time, timed alone with HIP events."""
+    import torch.distributed as dist
+    from probtalk_amd import _lib
+    from probtalk_amd.synthetic import build_pipeline
+    L = _lib.lib()
+    pred, _ = build_pipeline(seed=0)
+    vq = pred.VQ.eval()
+    B, T = (a.batch if a.batch != 512 else 256), 88
+    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    x = torch.randn(B, 376, T, device=dev, generator=g)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        with torch.no_grad():
+            return vq(x, result_form="full")
+
+    dt, (z, qo, rec) = time_steps(step, fence, a.steps, a.warmup, world, dev)
+    assert bool(torch.isfinite(rec).all()) and tuple(rec.shape) == (B, 376, T)
+    res = {"metric": "generated motion frames/sec (PQ-VAE encode+quantize+decode)", "value": world * B * T * a.steps / dt,
+           "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "configs[1]: PQ-VAE (config/vq.json) encode -> 4 x 128-code product quantizer -> decode, fp32, "
+                                  "bit-exact code indices", "clips_per_step_per_gpu": B, "frames_per_clip": T,
+                      "parallelism": f"dp{world}: clips sharded over ranks"}}
+    if rank == 0 and not a.no_roofline:
+        torch.cuda.synchronize()
+        _lib.check(L.pt_prof_enable(1))
+        step()
+        torch.cuda.synchronize()
+        ms, fl, ln = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int * 8)()
+        _lib.check(L.pt_prof_read(ms, fl, ln))
+        _lib.check(L.pt_prof_enable(0))
+        tot_ms, tot_fl, tot_n = sum(ms[i] for i in range(3)), sum(fl[i] for i in range(3)), sum(ln[i] for i in range(3))
+        peak, kname = f32_peak()
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                           "kernel": kname + ", all launches of one step", "launches_per_step": tot_n,
+                           "avg_launch_ms": tot_ms / max(tot_n, 1), "kernel_ms_per_step": tot_ms,
+                           "whole_step": {"algorithmic_tflop": MFLOP_PER_FRAME_VQVAE * 1e6 * B * T / 1e12,
+                                          "achieved_tflops": MFLOP_PER_FRAME_VQVAE * 1e6 * B * T / 1e12 / (1e-3 * res["ms_per_step"])}}
+        # the quantizer alone: pq_search_kernel on this step's latent rows, and on the bench batch of the pipeline
+        # (512 clips x 37 latent steps) for a launch long enough to read a rate from
+        cb = vq.vq_layer._codebooks(dev)
+        Gq, K, D = cb.shape
+        quant = {}
+        for tag, rows in (("this step", B * (T // 8)), ("512 clips x 300 frames", 512 * 37), ("262,144 rows", 262144)):
+            zc = torch.randn(rows, Gq * D, device=dev, generator=g)
+            qc = torch.empty_like(zc)
+            idx = torch.empty(rows, Gq, dtype=torch.int64, device=dev)
+
+            def run():
+                _lib.check(L.pt_pq_search_cl(_lib.ptr(zc), Gq * D, _lib.ptr(cb), rows, Gq, D, K, _lib.ptr(idx), _lib.ptr(qc), Gq * D,
+                                             _lib.stream()))
+            for _ in range(3):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 20
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(n):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / n
+            gbs = rows * PQ_BYTES_PER_LATENT_STEP / (us * 1e-6) / 1e9
+            tfl = 2.0 * rows * Gq * K * D / (us * 1e-6) / 1e12
+            quant[tag] = {"latent_rows": rows, "launch_us": us, "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS,
+                          "distance_tflops_fp32_mfma": tfl, "frac_of_fp32_mfma_peak": tfl / PEAK_F32_MFMA_TFLOPS}
+        res["quantizer_roofline"] = {"kernel": "pt::pq_search_kernel (distances on fp32 MFMA, wave argmin, fused gather)",
+                                     "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                     "algorithmic_bytes_per_latent_step": PQ_BYTES_PER_LATENT_STEP,
+                                     "timed_as": "torch.cuda.Event around 20 back-to-back launches on the launch stream, "
+                                                 "per row count", "by_rows": quant}
+    if rank == 0:
+        print(json.dumps(res), flush=True)
 
 
 def train_bench(a, rank, world, dev):
@@ -142,9 +249,10 @@ def gemm_roofline(pred, ref, inputs, dtype, ms_per_step, B, T):
     names = ("f32 128x128", "f32 64x128", "f32 64x64", "bf16 conv stacks: 256x256 lds-dma tap-GEMM (conv8_kernel) + 4-wave 128x128", "bf16 64x128", "bf16 64x64",
              "bf16 256x256 8-phase lds-dma (gemm8_kernel)", "bf16 N=512 row-complete +LN epilogues (gemm_row_kernel, sublayer_kernel)")
     dom = range(3, 8) if dtype == "bf16" else range(0, 3)     # the dominant kernel family of this mode
-    peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-    kname = "pt::gemm_row_kernel + pt::gemm8_kernel + pt::conv8_kernel + pt::gemm_bf16_kernel (bf16 MFMA GEMMs of the transformers and conv stacks)" \
-        if dtype == "bf16" else "pt::gemm_f32_kernel (tap-GEMM, fp32 MFMA 32x32x2)"
+    peak = PEAK_BF16_MFMA_TFLOPS
+    kname = "pt::gemm_row_kernel + pt::gemm8_kernel + pt::conv8_kernel + pt::gemm_bf16_kernel (bf16 MFMA GEMMs of the transformers and conv stacks)"
+    if dtype != "bf16":
+        peak, kname = f32_peak()
     tot_ms, tot_fl, tot_n = sum(ms[i] for i in dom), sum(fl[i] for i in dom), sum(ln[i] for i in dom)
     ach = tot_fl / (tot_ms * 1e-3) / 1e12
     step_tflop = MFLOP_PER_FRAME * 1e6 * B * T / 1e12
@@ -165,8 +273,9 @@ def gemm_roofline(pred, ref, inputs, dtype, ms_per_step, B, T):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=("infer", "train"), default="infer",
-                    help="infer (default): the metric's full pipeline; train: configs[4] predictor training step")
+    ap.add_argument("--workload", choices=("infer", "train", "vqvae"), default="infer",
+                    help="infer (default): the metric's full pipeline; train: configs[4] predictor training step; "
+                         "vqvae: configs[1] PQ-VAE encode -> quantize -> decode, 256 clips x 88 frames, fp32")
     ap.add_argument("--gpus", type=int, default=None,
                     help="ranks (one process per GPU). Without WORLD_SIZE in the environment and N > 1 this process spawns "
                          "the N ranks itself; under torch.distributed.run it must equal WORLD_SIZE")
@@ -184,6 +293,9 @@ def main():
                     help="replay the step from one captured HIP graph (probtalk_amd/graphs.py): for small, launch-bound batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline", action="store_true",
+                    help="N > 1: run rank 0's per-launch roofline pass too (off by default there: the other ranks would sit in a "
+                         "barrier for its duration)")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-arithmetic leg of the default bf16 run")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="library switch for A/B runs (pt_set_option: resid_bf16, fused_tail, small_rows, row_tile, ...)")
@@ -221,8 +333,15 @@ def main():
         from probtalk_amd import _lib
         name, _, val = kv.partition("=")
         _lib.check(_lib.lib().pt_set_option(name.encode(), int(val)))
-    if a.workload == "train":
-        train_bench(a, rank, world, dev)
+    if world > 1 and rank == 0:
+        # first contact with RCCL over xGMI happens on the driver's node: say what it runs on
+        try:
+            print(f"bench.py: world {world}, backend {backend}, RCCL/NCCL {torch.cuda.nccl.version()}, rank {rank} -> "
+                  f"{torch.cuda.get_device_name(local_rank)} (cuda:{local_rank})", file=sys.stderr, flush=True)
+        except Exception as e:  # informational only
+            print(f"bench.py: world {world}, backend {backend} ({e})", file=sys.stderr, flush=True)
+    if a.workload in ("train", "vqvae"):
+        (train_bench if a.workload == "train" else vqvae_bench)(a, rank, world, dev)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -281,11 +400,11 @@ def main():
                    "parallelism": f"dp{world}: clips sharded over ranks, outputs gathered to rank 0 over RCCL"},
     }
 
-    if rank == 0 and not a.no_roofline:
+    if rank == 0 and not a.no_roofline and (world == 1 or a.roofline):
         res["roofline"] = gemm_roofline(pred, ref, (aud, gt, mask, ids), a.dtype, res["ms_per_step"], B, T)
         # HBM traffic of the same kernels from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
         # this process): launch-weighted mean bytes per launch, FETCH_SIZE doubled as the microarch guide prescribes
-        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", r, "bf16_pmc_summary.json") for r in ("r2", "r1"))
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", r, "bf16_pmc_summary.json") for r in ("r3", "r2", "r1"))
                          if os.path.exists(q)), None)
         if a.dtype == "bf16" and pmc_path:
             with open(pmc_path) as f:
@@ -307,7 +426,8 @@ def main():
                                  torch.cuda.synchronize, k32, 1, 1, dev)
         assert bool(torch.isfinite(out32).all()), "non-finite fp32 output"
         res["fp32"] = {"value": B * T * k32 / dt32, "unit": "frames/s", "steps": k32, "warmup": 1, "ms_per_step": 1e3 * dt32 / k32,
-                       "dtype": "f32", "note": "same workload with fp32 MFMA everywhere (pt_model_set_precision 0)"}
+                       "dtype": "f32", "note": "same workload in the reference's arithmetic (pt_model_set_precision 0): fp32 "
+                                               "operands and accumulation, tap-GEMMs on " + f32_peak()[1]}
         if not a.no_roofline:
             r32 = gemm_roofline(pred32, ref32, (aud, gt, mask, ids), "f32", res["fp32"]["ms_per_step"], B, T)
             res["fp32"]["roofline"] = {k: r32[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "launches_per_step",

@@ -261,15 +261,21 @@ int pt_train_add(const float* a, const float* b, float* out, size_t n, void* str
  * latent rows, Laplace smoothing, dead-code re-seeding from the first K latent rows, new codebooks.  z rows [rows, ldz]
  * (G*D used columns), idx int64 [rows, G]; counts [G,K] and dw [G,K,D] are scratch; cs_hidden [G,K], dw_hidden [G,K,D],
  * emb [G,K,D] are the module's buffers (ema_cluster_size.i.hidden, ema_dw.i.hidden, embeddings_i) stacked over i;
- * counter = the EMA modules' call count including this call.  rows >= K required. */
+ * counter = the EMA modules' call count including this call.
+ * rows < K: `_tile` (vqvae_modules.py:571-580) repeats the batch and adds N(0,1) * 0.01 / sqrt(D): seed row k = chunk
+ * k mod rows + noise.  tile_noise [G][K][D] (device) injects the N(0,1) draws (row k of group g = row k of the g-th
+ * torch.randn_like of the reference: the parity mode); NULL = generated in the kernel from tile_seed. */
 int pt_train_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw,
-                    float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, void* stream);
+                    float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, const float* tile_noise,
+                    uint64_t tile_seed, void* stream);
 /* The same with share_code=True (vqvae_modules.py:496-512): the chunks of all G groups update ONE codebook.  counts [K] and
  * dw [K,D] are scratch; cs_hidden [K], dw_hidden [K,D], emb [K,D] are ema_cluster_size.hidden, ema_dw.hidden and
  * embeddings_0.  Dead codes are re-seeded from the first K chunks in group-major order (all rows of group 0, then group
- * 1, ...: line 498's flat_x); the EMA state is NOT reset (the share_code branch has no lines 529-532).  rows*G >= K. */
+ * 1, ...: line 498's flat_x); the EMA state is NOT reset (the share_code branch has no lines 529-532).  rows*G < K: tiled
+ * with noise as above, tile_noise [K][D]. */
 int pt_train_pq_ema_shared(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw,
-                           float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, void* stream);
+                           float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, const float* tile_noise,
+                           uint64_t tile_seed, void* stream);
 /* VectorQuantizerEMA.forward train branch (vqvae_modules.py:323-334), the legacy single codebook of s2g_body_vq: the same
  * EMA update for ONE codebook [K, D] without dead-code re-seeding; any number of latent rows; K may exceed 1024. */
 int pt_train_vq_ema(const float* z, int ldz, const int64_t* idx, int rows, int D, int K, float* counts, float* dw,
@@ -316,6 +322,9 @@ int pt_postprocess_poses(const float* pred, int B, int T, const float* mean, con
  *                        one-workgroup-per-CU row kernel everywhere (bit-identical results; the two-workgroup form
  *                        measured 8-30 % slower per launch)
  *   "row2_min_rows"      rows from which row2 applies (default 20480 = 80 rows x 256 CUs)
+ *   "split_bf16"         1 (default) the fp32 tap-GEMM (fp32 mode, PQ-VAE encoder, training forward / input gradients)
+ *                        runs on the bf16 matrix cores with each fp32 operand split into three bf16 terms and six
+ *                        products per pair (fp32 accuracy at 2.7 x the fp32 MFMA rate); 0 = the fp32 MFMA kernel
  * Unknown names and out-of-range values are errors (non-zero return, pt_last_error). */
 int pt_set_option(const char* name, int value);
 int pt_get_option(const char* name, int* value);

@@ -11,6 +11,8 @@ tools/make_golden_train.py from the imported reference with its Dropout modules 
 import contextlib
 import math
 
+import numpy as np
+
 import torch
 import torch.nn.functional as F
 
@@ -90,7 +92,21 @@ def adamw_step(p, g, m, v, step, lr, betas=(0.9, 0.99), eps=1e-8, wd=1e-2):
 
 
 # ------------------------------------------------------------------------------------------------ PQ-VAE train step
-def pq_train(sd, p, z, groups, commitment_cost=0.25, decay=0.99, eps=1e-5, counter=1, share_code=False):
+def tile(x, K, noise):
+    """ProductQuantization._tile (vqvae_modules.py:571-580): a batch of fewer chunks than codes is repeated and N(0,1) *
+    0.01 / sqrt(D) is added; `noise` stands for torch.randn_like(out) (only its first K rows reach the caller)."""
+    nb, D = x.shape
+    if nb >= K:
+        return x
+    reps = (K + nb - 1) // nb
+    out = x.repeat(reps, 1)
+    std = 0.01 / np.sqrt(D)
+    full = torch.zeros_like(out)
+    full[:K] = noise                         # rows K.. of the reference's draw are never read (code_rand = out[:K])
+    return out + full * std
+
+
+def pq_train(sd, p, z, groups, commitment_cost=0.25, decay=0.99, eps=1e-5, counter=1, share_code=False, tile_noise=None):
     """ProductQuantization.forward, training branch (vqvae_modules.py:470-487,495-544; share_code: 496-512).
     -> (quantized with straight-through gradient (B,C,W), commitment loss, indices (BW, G), updated buffers).
     share_code: every group searches its own buffer embeddings_i (they alias one tensor only until the module is moved
@@ -100,7 +116,8 @@ def pq_train(sd, p, z, groups, commitment_cost=0.25, decay=0.99, eps=1e-5, count
     x = z.permute(0, 2, 1)
     flat = x.reshape(-1, groups, D)
     K = sd[f"{p}embeddings_0"].shape[0]
-    assert flat.shape[0] * (groups if share_code else 1) >= K, "the noisy re-tiling of short batches (571-580) is not restated"
+    if flat.shape[0] * (groups if share_code else 1) < K:
+        assert tile_noise is not None, "fewer chunks than codes: pass _tile's N(0,1) draws ([G,K,D], or [K,D] with share_code)"
     idx, q, new = [], [], {}
     for i in range(groups):
         emb = sd[f"{p}embeddings_{i}"]
@@ -125,7 +142,7 @@ def pq_train(sd, p, z, groups, commitment_cost=0.25, decay=0.99, eps=1e-5, count
             usage = (cs.view(K, 1) >= 1.0).float()
             new[f"{p}ema_dw.hidden"] = dw_h
             new[f"{p}ema_cluster_size.hidden"] = cs_h
-            new[f"{p}embeddings_0"] = usage * normalised + (1 - usage) * all_x[:K]
+            new[f"{p}embeddings_0"] = usage * normalised + (1 - usage) * tile(all_x, K, tile_noise)[:K]
         for i in range(groups if not share_code else 0):
             enc = F.one_hot(idx[i], K).to(flat.dtype)
             cs_h = sd[f"{p}ema_cluster_size.{i}.hidden"].clone()
@@ -136,7 +153,7 @@ def pq_train(sd, p, z, groups, commitment_cost=0.25, decay=0.99, eps=1e-5, count
             dw_h = sd[f"{p}ema_dw.{i}.hidden"].clone()
             dw_h.sub_((dw_h - enc.t() @ flat[:, i].detach()) * (1 - decay))
             normalised = (dw_h / corr) / cs.reshape(-1, 1)
-            code_rand = flat[:K, i].detach()
+            code_rand = tile(flat[:, i].detach(), K, None if tile_noise is None else tile_noise[i])[:K]
             usage = (cs.view(K, 1) >= 1.0).float()
             new[f"{p}ema_dw.{i}.hidden"] = usage * dw_h + (1 - usage) * code_rand
             new[f"{p}ema_cluster_size.{i}.hidden"] = cs_h * usage.view(-1) + (1 - usage).view(-1)

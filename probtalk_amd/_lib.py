@@ -84,7 +84,7 @@ def _proto(lib):
     lib.pt_train_clip_coef.argtypes = [vp, f, vp, vp, vp]
     lib.pt_train_adamw.argtypes = [vp, vp, vp, vp, sz, vp, f, f, f, f, f, i, vp]
     lib.pt_train_add.argtypes = [vp, vp, vp, sz, vp]
-    lib.pt_train_pq_ema.argtypes = [vp, i, vp, i, i, i, i, vp, vp, vp, vp, vp, f, f, i, vp]
+    lib.pt_train_pq_ema.argtypes = [vp, i, vp, i, i, i, i, vp, vp, vp, vp, vp, f, f, i, vp, C.c_uint64, vp]
     lib.pt_train_pq_ema_shared.argtypes = lib.pt_train_pq_ema.argtypes
     lib.pt_train_vq_ema.argtypes = [vp, i, vp, i, i, i, vp, vp, vp, vp, vp, f, f, i, vp]
     lib.pt_train_vq_losses.argtypes = [vp, i, vp, i, i, i, i, vp, vp, i, f, vp, vp, i, vp]

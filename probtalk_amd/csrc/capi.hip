@@ -38,7 +38,7 @@ int launch_add(const float* a, const float* b, float* out, size_t n, hipStream_t
 int launch_attention_bf16(const unsigned short* Q, int ldq, const unsigned short* K, int ldk, const unsigned short* V, int ldv, unsigned short* O, int ldo, int B, int Nq, int Nk, int H, hipStream_t s);
 int launch_maskgit_noise(unsigned long long seed, int step, int B, int N, int V, float* q, float* g, hipStream_t s);
 int launch_maskgit_bits(const unsigned* bits, int n, float* u, float* q, float* g, hipStream_t s);
-int launch_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw, float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, hipStream_t s, int reseed);
+int launch_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw, float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, hipStream_t s, int reseed, const float* tile_noise, unsigned long long tile_seed);
 int launch_vq_losses(const float* pred, int ldp, const float* gt, int ldg, int B, int T, int nparts, const int* bounds, const float* weights, int vel_cols, float beta, float* sums, float* dpred, int lddp, hipStream_t s, const float* nmask, float t_nmask, int l1);
 int launch_sqdiff(const float* a, const float* b, size_t n, float* out, hipStream_t s);
 int launch_commit_bwd(const float* dq, const float* z, const float* q, const float* g, float coef, size_t n, float* dz, hipStream_t s);
@@ -81,10 +81,11 @@ constexpr OptSpec g_opt_spec[pt::OPT_COUNT] = {
     {"resid_bf16", 1, 0, 1},          {"fused_tail", -1, -1, 1}, {"small_rows", 2048, 0, 1 << 30},
     {"row_tile", 0, 0, 10},           {"attn_train_rowwise", 0, 0, 1}, {"conv8", 1, 0, 1},
     {"store_overlap", 1, 0, 1},       {"row2", 0, 0, 1},         {"row2_min_rows", 20480, 0, 1 << 30},
+    {"split_bf16", 1, 0, 1},
 };
 int g_opt[pt::OPT_COUNT] = {g_opt_spec[0].def, g_opt_spec[1].def, g_opt_spec[2].def, g_opt_spec[3].def, g_opt_spec[4].def,
-                            g_opt_spec[5].def, g_opt_spec[6].def, g_opt_spec[7].def, g_opt_spec[8].def};
-static_assert(pt::OPT_COUNT == 9, "option table out of step with pt_common.h");
+                            g_opt_spec[5].def, g_opt_spec[6].def, g_opt_spec[7].def, g_opt_spec[8].def, g_opt_spec[9].def};
+static_assert(pt::OPT_COUNT == 10, "option table out of step with pt_common.h");
 int find_option(const char* name) {
   if (name)
     for (int i = 0; i < pt::OPT_COUNT; ++i)
@@ -521,16 +522,21 @@ int pt_train_add(const float* a, const float* b, float* out, size_t n, void* str
   return launch_add(a, b, out, n, (hipStream_t)stream);
 }
 int pt_train_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw,
-                    float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, void* stream) {
-  return launch_pq_ema(z, ldz, idx, rows, G, D, K, counts, dw, cs_hidden, dw_hidden, emb, decay, eps, counter, (hipStream_t)stream, 1);
+                    float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, const float* tile_noise,
+                    uint64_t tile_seed, void* stream) {
+  return launch_pq_ema(z, ldz, idx, rows, G, D, K, counts, dw, cs_hidden, dw_hidden, emb, decay, eps, counter, (hipStream_t)stream, 1,
+                       tile_noise, tile_seed);
 }
 int pt_train_pq_ema_shared(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw,
-                           float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, void* stream) {
-  return launch_pq_ema(z, ldz, idx, rows, G, D, K, counts, dw, cs_hidden, dw_hidden, emb, decay, eps, counter, (hipStream_t)stream, 2);
+                           float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, const float* tile_noise,
+                           uint64_t tile_seed, void* stream) {
+  return launch_pq_ema(z, ldz, idx, rows, G, D, K, counts, dw, cs_hidden, dw_hidden, emb, decay, eps, counter, (hipStream_t)stream, 2,
+                       tile_noise, tile_seed);
 }
 int pt_train_vq_ema(const float* z, int ldz, const int64_t* idx, int rows, int D, int K, float* counts, float* dw,
                     float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, void* stream) {
-  return launch_pq_ema(z, ldz, idx, rows, 1, D, K, counts, dw, cs_hidden, dw_hidden, emb, decay, eps, counter, (hipStream_t)stream, 0);
+  return launch_pq_ema(z, ldz, idx, rows, 1, D, K, counts, dw, cs_hidden, dw_hidden, emb, decay, eps, counter, (hipStream_t)stream, 0,
+                       nullptr, 0);
 }
 int pt_train_vq_losses(const float* pred, int ldp, const float* gt, int ldg, int B, int T, int nparts, const int* bounds,
                        const float* weights, int vel_cols, float beta, float* sums, float* dpred, int lddp, void* stream) {

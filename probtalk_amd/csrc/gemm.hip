@@ -25,6 +25,64 @@ constexpr int LDS_ST = BK + 4;  // floats per LDS row
 
 __device__ __forceinline__ float act_leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// Epilogue shared by the fp32-MFMA kernel and the split-bf16 kernel (same 32x32 accumulator layout):
+// D[i][j]: col j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int MI, int NI>
+__device__ __forceinline__ void tap_epilogue(const GemmArgs& p, f32x16 (&acc)[MI][NI], const int m0, const int n0, const int wm,
+                                             const int wn, const int lane) {
+  const bool plain_rows = (p.out_stride == 1 && p.out_off == 0 && p.Lgrid == p.Lout);
+  const int lcol = lane & 31, lrow = 4 * (lane >> 5);
+  const bool gated = (p.act == ACT_GATED);
+  const int n_out = gated ? p.N / 2 : p.N;
+
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + lrow;
+      if (m >= p.M) continue;
+      int orow = m;
+      if (!plain_rows) {
+        const int b = m / p.Lgrid;
+        orow = b * p.Lout + (m - b * p.Lgrid) * p.out_stride + p.out_off;
+      }
+      float* crow = p.C + (size_t)orow * p.ldc;
+      if (gated) {
+        if constexpr (NI % 2 == 0) {
+#pragma unroll
+          for (int pr = 0; pr < NI / 2; ++pr) {
+            const int nperm = n0 + wn * 32 * NI + pr * 64 + lcol;  // 'a' row; 'b' row is +32
+            const int col = (n0 + wn * 32 * NI + pr * 64) / 2 + lcol;
+            if (col < n_out) {
+              float va = acc[mi][2 * pr][r], vb = acc[mi][2 * pr + 1][r];
+              if (p.bias) { va += p.bias[nperm]; vb += p.bias[nperm + 32]; }
+              const float g = tanhf(va) * (1.f / (1.f + expf(-vb)));
+              crow[col] = g;
+            } else if (col < p.zero_to) {
+              crow[col] = 0.f;
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int col = n0 + wn * 32 * NI + ni * 32 + lcol;
+          if (col < n_out) {
+            float v = acc[mi][ni][r];
+            if (p.bias) v += p.bias[col];
+            if (p.pe) v = (float)((double)v + p.pe[(size_t)(orow % p.pe_period) * p.N + col]);
+            if (p.Res) v += p.Res[(size_t)orow * p.ldr + col];
+            if (p.act == ACT_LEAKY) v = act_leaky(v, p.slope);
+            crow[col] = v;
+          } else if (col < p.zero_to) {
+            crow[col] = 0.f;
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int MI, int NI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p, const int tiles_n, const int nwg) {
   constexpr int BM = 64 * MI, BN = 64 * NI;
@@ -128,58 +186,187 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p, const i
     __syncthreads();
   }
 
-  // ---- epilogue: D[i][j]: col j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const bool plain_rows = (p.out_stride == 1 && p.out_off == 0 && p.Lgrid == p.Lout);
-  const int lcol = lane & 31, lrow = 4 * (lane >> 5);
-  const bool gated = (p.act == ACT_GATED);
-  const int n_out = gated ? p.N / 2 : p.N;
+  tap_epilogue<MI, NI>(p, acc, m0, n0, wm, wn, lane);
+}
 
+// ---------------------------------------------------------------------------
+// The same tap-GEMM with fp32-accurate arithmetic on the bf16 matrix cores (round 3).
+//
+// fp32 MFMA runs at the fp32 vector rate (1/16 of bf16).  An fp32 value is the exact sum of three bf16 values
+// (x = x0 + x1 + x2: x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1); 3 x 8 significand bits cover the 24), so
+//   a * b = a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0) + [a1 b2 + a2 b1 + a2 b2 <= 3 * 2^-24 |a b|, dropped],
+// six bf16 products (each exact in the fp32 accumulator) in place of one fp32 product: 16 / 6 = 2.7 x the fp32 MFMA
+// rate at fp32 accuracy.  The operands stay fp32 in HBM (weights and activations as the fp32 mode has them): the split
+// happens on the way into LDS, where a stage holds three bf16 planes per operand.
+//
+// 256 threads = 4 waves (2 x 2), wave tile (32 MI) x (32 NI) of v_mfma_f32_32x32x16_bf16 accumulators (the 32x32 output
+// layout of the fp32 kernel, so the epilogue is shared); BK = 32 per stage = two k-steps of 16.  LDS: ONE stage of
+// [3 planes][BM + BN rows][64 B + 16 B pad] (rows 80 B apart: conflict-free ds_read_b128 fragment reads), 60 KB at
+// 128 x 128: two workgroups per CU, so one splits and stores its next stage (VALU) while the other's MFMAs run.  The
+// global loads run two stages ahead in two register sets.  Measured and not kept: one workgroup per CU with two LDS
+// stages and the split interleaved between the MFMAs (80-92 TFLOP/s-equivalent against 115-149).  What bounds it is the
+// operand stream, not the matrix pipe: fp32 operands at 128 x 128 are 32 FLOP per byte staged, a quarter of the
+// 256 x 256 bf16 GEMM's.
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+constexpr int S_ROW = 80;                 // bytes per LDS row of one plane (32 bf16 + pad)
+
+// x -> (x0, x1, x2) as packed bf16x4 (8 bytes each)
+__device__ __forceinline__ void split3(const f32x4 v, u32x2_t& h, u32x2_t& m, u32x2_t& l) {
+  const bf16x4_t b0 = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  f32x4 r1;
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
+  for (int e = 0; e < 4; ++e) r1[e] = v[e] - (float)b0[e];
+  const bf16x4_t b1 = {(__bf16)r1[0], (__bf16)r1[1], (__bf16)r1[2], (__bf16)r1[3]};
+  f32x4 r2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + lrow;
-      if (m >= p.M) continue;
-      int orow = m;
-      if (!plain_rows) {
-        const int b = m / p.Lgrid;
-        orow = b * p.Lout + (m - b * p.Lgrid) * p.out_stride + p.out_off;
-      }
-      float* crow = p.C + (size_t)orow * p.ldc;
-      if (gated) {
-        if constexpr (NI % 2 == 0) {
+  for (int e = 0; e < 4; ++e) r2[e] = r1[e] - (float)b1[e];
+  const bf16x4_t b2 = {(__bf16)r2[0], (__bf16)r2[1], (__bf16)r2[2], (__bf16)r2[3]};
+  h = __builtin_bit_cast(u32x2_t, b0);
+  m = __builtin_bit_cast(u32x2_t, b1);
+  l = __builtin_bit_cast(u32x2_t, b2);
+}
+
+template <int MI, int NI>
+__global__ __launch_bounds__(256, 2) void gemm_f32s_kernel(const GemmArgs p, const int tiles_n, const int nwg) {
+  constexpr int BM = 64 * MI, BN = 64 * NI;
+  constexpr int AI = 2 * MI, BI = 2 * NI;  // float4 loads per thread per stage
+  constexpr int ROWS = BM + BN;
+  constexpr int PLANE = ROWS * S_ROW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
+
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c4 = tid & 7, r0 = tid >> 3;
+
+  int a_l[AI], a_rb[AI];
 #pragma unroll
-          for (int pr = 0; pr < NI / 2; ++pr) {
-            const int nperm = n0 + wn * 32 * NI + pr * 64 + lcol;  // 'a' row; 'b' row is +32
-            const int col = (n0 + wn * 32 * NI + pr * 64) / 2 + lcol;
-            if (col < n_out) {
-              float va = acc[mi][2 * pr][r], vb = acc[mi][2 * pr + 1][r];
-              if (p.bias) { va += p.bias[nperm]; vb += p.bias[nperm + 32]; }
-              const float g = tanhf(va) * (1.f / (1.f + expf(-vb)));
-              crow[col] = g;
-            } else if (col < p.zero_to) {
-              crow[col] = 0.f;
-            }
-          }
-        }
-      } else {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const int col = n0 + wn * 32 * NI + ni * 32 + lcol;
-          if (col < n_out) {
-            float v = acc[mi][ni][r];
-            if (p.bias) v += p.bias[col];
-            if (p.pe) v = (float)((double)v + p.pe[(size_t)(orow % p.pe_period) * p.N + col]);
-            if (p.Res) v += p.Res[(size_t)orow * p.ldr + col];
-            if (p.act == ACT_LEAKY) v = act_leaky(v, p.slope);
-            crow[col] = v;
-          } else if (col < p.zero_to) {
-            crow[col] = 0.f;
-          }
-        }
-      }
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    if (m < p.M) {
+      const int b = m / p.Lgrid;
+      a_l[i] = (m - b * p.Lgrid) * p.in_stride;
+      a_rb[i] = b * p.Lin;
+    } else {
+      a_l[i] = -(1 << 28);
+      a_rb[i] = 0;
     }
   }
+  const int kch = p.K / BK;
+  const int nk = p.ntaps * kch;
+
+  // two register sets: the global loads run TWO stages ahead of the MFMAs (a stage of 48 bf16 MFMAs per wave is shorter
+  // than an HBM round trip under load); stage s travels through set s & 1
+  f32x4 ra[2][AI], rb[2][BI];
+  int tap = 0, kc = 0;
+  auto gload = [&](const int set) {
+    const int d = p.tap_d[tap];
+    const float* Wt = p.W + (size_t)p.tap_w[tap] * p.Npad * p.K;
+    const int k = kc * BK + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int l = a_l[i] + d;
+      if ((unsigned)l < (unsigned)p.Lin)
+        ra[set][i] = *reinterpret_cast<const f32x4*>(p.A + (size_t)(a_rb[i] + l) * p.lda + k);
+      else
+        ra[set][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      rb[set][i] = *reinterpret_cast<const f32x4*>(Wt + (size_t)(n0 + r0 + 32 * i) * p.K + k);
+    if (++kc == kch) { kc = 0; ++tap; }
+  };
+  // split + store of ONE of the thread's AI + BI float4 (rows r0 + 32 i, 4 consecutive k -> 8 bytes per plane) into LDS
+  // buffer `buf`
+  auto lstore1 = [&](const int set, const int buf, const int i) {
+    const f32x4 v = i < AI ? ra[set][i] : rb[set][i - AI];
+    const int row = i < AI ? r0 + 32 * i : BM + r0 + 32 * (i - AI);
+    u32x2_t h, m, l;
+    split3(v, h, m, l);
+    unsigned char* dst = smem_s + buf * (3 * PLANE) + row * S_ROW + c4 * 8;
+    *reinterpret_cast<u32x2_t*>(dst) = h;
+    *reinterpret_cast<u32x2_t*>(dst + PLANE) = m;
+    *reinterpret_cast<u32x2_t*>(dst + 2 * PLANE) = l;
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  gload(0);
+#pragma unroll
+  for (int i = 0; i < AI + BI; ++i) lstore1(0, 0, i);
+  __syncthreads();
+  if (nk > 1) gload(1);
+  if (nk > 2) gload(0);
+
+  // fragment of v_mfma_f32_32x32x16_bf16: lane -> row (lane & 31), 8 consecutive k at 8 * (lane >> 5)
+  const int frag_off = (lane & 31) * S_ROW + 16 * (lane >> 5);
+  const unsigned char* As = smem_s + (wm * 32 * MI) * S_ROW + frag_off;
+  const unsigned char* Bs = smem_s + (BM + wn * 32 * NI) * S_ROW + frag_off;
+  // One stage: MFMAs on the LDS image of stage `it`; then stage it+1 (register set `nset`) is split and stored between
+  // two barriers and the loads of stage it+3 go into the set that was just stored.  Two workgroups share a CU: one
+  // splits and stores (VALU, LDS) while the other's MFMAs run.
+  auto stage = [&](const int it, const int nset, const bool store_next) {
+#pragma unroll
+    for (int u = 0; u < BK / 16; ++u) {
+      bf16x8_t a[3][MI], b[3][NI];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[pl][mi] = *reinterpret_cast<const bf16x8_t*>(As + pl * PLANE + mi * 32 * S_ROW + u * 32);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[pl][ni] = *reinterpret_cast<const bf16x8_t*>(Bs + pl * PLANE + ni * 32 * S_ROW + u * 32);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          f32x16 c = acc[mi][ni];
+          // smallest terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][mi], b[0][ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[2][ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mi], b[1][ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mi], b[0][ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[1][ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[0][ni], c, 0, 0, 0);
+          acc[mi][ni] = c;
+        }
+    }
+    __syncthreads();                      // every wave is done reading the stage
+    if (store_next) {
+#pragma unroll
+      for (int i = 0; i < AI + BI; ++i) lstore1(nset, 0, i);
+      __syncthreads();
+      if (it + 3 < nk) gload(nset);
+    }
+  };
+  int it = 0;
+  for (; it + 2 < nk; it += 2) {
+    stage(it, 1, true);
+    stage(it + 1, 0, true);
+  }
+  if (it + 1 < nk) {
+    stage(it, 1, true);
+    stage(it + 1, 0, false);
+  } else {
+    stage(it, 1, false);
+  }
+  tap_epilogue<MI, NI>(p, acc, m0, n0, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -231,14 +418,18 @@ template <int MI, int NI>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
   constexpr int BM = 64 * MI, BN = 64 * NI;
   constexpr size_t smem = 2 * (size_t)(BM + BN) * LDS_ST * sizeof(float);
-  PT_ENSURE_LDS((gemm_f32_kernel<MI, NI>), smem);
+  constexpr size_t smem_s = 3 * (size_t)(BM + BN) * S_ROW;
+  const bool split = option(OPT_SPLIT_BF16) == 1;
+  if (split) PT_ENSURE_LDS((gemm_f32s_kernel<MI, NI>), smem_s);
+  else PT_ENSURE_LDS((gemm_f32_kernel<MI, NI>), smem);
   const int tiles_m = (a.M + BM - 1) / BM;
   const int tiles_n = (a.N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
   void* tok = nullptr;
   if (g_prof_on) prof_record_begin(s, a.flops > 0 ? a.flops : 2.0 * a.M * a.N * a.K * a.ntaps,
                                    (MI == 2 && NI == 2) ? 0 : (NI == 2 ? 1 : 2), &tok);
-  PT_LAUNCH((gemm_f32_kernel<MI, NI>), dim3(nwg), dim3(256), smem, s, a, tiles_n, nwg);
+  if (split) PT_LAUNCH((gemm_f32s_kernel<MI, NI>), dim3(nwg), dim3(256), smem_s, s, a, tiles_n, nwg);
+  else PT_LAUNCH((gemm_f32_kernel<MI, NI>), dim3(nwg), dim3(256), smem, s, a, tiles_n, nwg);
   if (tok) prof_record_end(s, tok);
   return 0;
 }

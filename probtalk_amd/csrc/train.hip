@@ -1171,13 +1171,25 @@ __global__ __launch_bounds__(256) void pq_ema_accum_kernel(const float* __restri
   }
 }
 // hidden -= (hidden - value)(1 - decay); average = hidden / (1 - decay^counter); Laplace smoothing of the cluster sizes;
-// codes whose smoothed size < 1 are re-seeded from the first K latent rows (`_tile`, 571-580, rows >= K) and their EMA
-// state reset (529-534).  One workgroup per group, one thread per code.
+// codes whose smoothed size < 1 are re-seeded from the first K latent rows (`_tile`, 571-580) and their EMA state reset
+// (529-534).  A batch with fewer chunks than codes is tiled with noise as `_tile` does (573-577): seed row k is chunk
+// k mod nb plus N(0,1) * 0.01 / sqrt(D), the N(0,1) draw taken from `noise` [groups][K][D] when given (the parity mode:
+// the first K rows of each torch.randn_like of the reference) or from a counter-based generator keyed by (seed, group,
+// code, column).  One workgroup per group, one thread per code.
+__device__ __forceinline__ float tile_normal(unsigned long long seed, unsigned g, unsigned k, unsigned d) {
+  // two 24-bit uniforms from a 64-bit mix of the counter, Box-Muller
+  unsigned long long x = seed ^ (0x9E3779B97F4A7C15ull * (((unsigned long long)g << 40) ^ ((unsigned long long)k << 20) ^ d) + 0xD1B54A32D192ED03ull);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+  const float u1 = ((float)((x >> 40) & 0xFFFFFF) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1]
+  const float u2 = (float)((x >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
 __global__ __launch_bounds__(1024) void pq_ema_finish_kernel(const float* __restrict__ counts, const float* __restrict__ dw,
                                                              const float* __restrict__ z, int ldz, int D, int K,
                                                              float* __restrict__ cs_hidden, float* __restrict__ dw_hidden,
                                                              float* __restrict__ emb, float one_minus_decay, float eps,
-                                                             float corr, int reseed, int rows) {
+                                                             float corr, int reseed, int rows, int nb, const float* __restrict__ noise,
+                                                             float tile_std, unsigned long long tile_seed) {
   // reseed = 1: ProductQuantization (dead codes re-seeded and their EMA state reset, 525-534); 0: VectorQuantizerEMA
   // (323-334, no re-seeding); 2: ProductQuantization with share_code (509-512): dead codes of the one code book are
   // re-seeded from the first K chunks of the group-major flat_x of line 498 (chunk k = group k / rows, row k % rows), the
@@ -1202,13 +1214,24 @@ __global__ __launch_bounds__(1024) void pq_ema_finish_kernel(const float* __rest
     const float avg = h / corr;
     const float sm = (avg + eps) / (n + (float)K * eps) * n;
     const bool used = !reseed || sm >= 1.0f;
-    const int seed_g = reseed == 2 ? k / rows : g, seed_row = reseed == 2 ? k - seed_g * rows : k;
+    // nb = chunks `_tile` sees (rows, or rows * G when the code book is shared); seed chunk of code k: k mod nb
+    const bool tiled = reseed && nb < K;
+    const int kc = tiled ? k % nb : k;
+    const int seed_g = reseed == 2 ? kc / rows : g, seed_row = reseed == 2 ? kc - seed_g * rows : kc;
     for (int d = 0; d < D; ++d) {
       const size_t o = ((size_t)g * K + k) * D + d;
       float hd = dw_hidden[o];
       hd -= (hd - dw[o]) * one_minus_decay;
       const float nrm = (hd / corr) / sm;
-      const float rnd = reseed ? z[(size_t)seed_row * ldz + seed_g * D + d] : 0.f;
+      float rnd = reseed ? z[(size_t)seed_row * ldz + seed_g * D + d] : 0.f;
+      if (tiled) {
+        // out + randn_like(out) * std (577): a rounded product, then a rounded sum (no fma), as torch computes it
+        const float nz = noise ? noise[o] : tile_normal(tile_seed, (unsigned)g, (unsigned)k, (unsigned)d);
+        // (hipcc contracts even __fmul_rn + __fadd_rn into one fma: the product goes through an opaque register first)
+        float prod = nz * tile_std;
+        asm volatile("" : "+v"(prod));
+        rnd = rnd + prod;
+      }
       dw_hidden[o] = (used || reseed == 2) ? hd : rnd;
       emb[o] = used ? nrm : rnd;
     }
@@ -1216,11 +1239,10 @@ __global__ __launch_bounds__(1024) void pq_ema_finish_kernel(const float* __rest
   }
 }
 int launch_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, int D, int K, float* counts, float* dw,
-                  float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, hipStream_t s, int reseed) {
-  PT_CHECK(z && idx && counts && dw && cs_hidden && dw_hidden && emb && G > 0 && D > 0 && K > 0, "pq_ema: bad argument");
-  PT_CHECK(!reseed || (reseed == 2 ? (long long)rows * G : (long long)rows) >= K,
-           "pq_ema: %d latent rows < %d codes (the reference's noisy re-tiling of short batches, vqvae_modules.py:573-577, "
-           "is not built)", rows, K);
+                  float* cs_hidden, float* dw_hidden, float* emb, float decay, float eps, int counter, hipStream_t s, int reseed,
+                  const float* tile_noise, unsigned long long tile_seed) {
+  PT_CHECK(z && idx && counts && dw && cs_hidden && dw_hidden && emb && G > 0 && D > 0 && K > 0 && rows > 0, "pq_ema: bad argument");
+  const long long nb = reseed == 2 ? (long long)rows * G : (long long)rows;    // chunks `_tile` sees
   PT_CHECK(counter >= 1 && decay > 0.f && decay < 1.f, "pq_ema: bad decay / counter");
   const int shared = reseed == 2, Gs = shared ? 1 : G;            // statistics and state of ONE code book when shared
   PT_HIP(hipMemsetAsync(counts, 0, sizeof(float) * Gs * K, s));
@@ -1230,8 +1252,9 @@ int launch_pq_ema(const float* z, int ldz, const int64_t* idx, int rows, int G, 
             D, K, counts, dw, shared);
   const float omd = (float)(1.0 - (double)decay);
   const float corr = (float)(1.0 - std::pow((double)decay, (double)counter));
+  const float tile_std = (float)(0.01 / std::sqrt((double)D));                  // vqvae_modules.py:575
   PT_LAUNCH(pq_ema_finish_kernel, dim3(Gs), dim3(std::min((K + 63) / 64 * 64, 1024)), 0, s, counts, dw, z, ldz, D, K, cs_hidden,
-            dw_hidden, emb, omd, eps, corr, reseed, rows);
+            dw_hidden, emb, omd, eps, corr, reseed, rows, (int)std::min<long long>(nb, 1 << 30), tile_noise, tile_std, tile_seed);
   return 0;
 }
 

@@ -258,6 +258,9 @@ class ProductQuantization(_QuantizerBase):
         if Cc != G * self.embedding_dim:
             raise RuntimeError(f"quantizer: input has {Cc} channels, codebooks cover {G}x{self.embedding_dim}")
         _train_tensors(self)
+        # `_tile`'s N(0,1) draws for a batch with fewer chunks than codes (vqvae_modules.py:573-577): tests inject them
+        # ([G,K,D], or [K,D] with share_code) as they inject the sampler's noise; otherwise the kernel draws its own
+        tile_noise = self.__dict__.pop("_pt_tile_noise", None)
         cb = torch.stack([getattr(self, n) for n in self._codebook_names()]).contiguous()
         z = T.to_rows(x, Cc)
         q, loss, idx = T.PQQuantizeTrain.apply(z, cb, self.commitment_cost)
@@ -265,7 +268,7 @@ class ProductQuantization(_QuantizerBase):
             self.ema_cluster_size.counter += 1
             self.ema_dw.counter += 1
             T.pq_ema_update_shared(z.detach(), idx, G, self.ema_cluster_size.hidden, self.ema_dw.hidden, self.embeddings_0,
-                                   self.ema_dw.decay, self.epsilon, self.ema_dw.counter)
+                                   self.ema_dw.decay, self.epsilon, self.ema_dw.counter, tile_noise=tile_noise)
             self.__dict__["_pt_cb"] = None
             self.__dict__["_pt_last_indices"] = idx.view(B, W, G)
             return QuantizationOutput(T.RowsToNCL.apply(q, B, Cc, W), loss)
@@ -273,7 +276,8 @@ class ProductQuantization(_QuantizerBase):
         dw = torch.stack([m.hidden for m in self.ema_dw]).contiguous()
         for m in list(self.ema_cluster_size) + list(self.ema_dw):
             m.counter += 1
-        T.pq_ema_update(z.detach(), idx, cs, dw, cb, self.ema_dw[0].decay, self.epsilon, self.ema_dw[0].counter)
+        T.pq_ema_update(z.detach(), idx, cs, dw, cb, self.ema_dw[0].decay, self.epsilon, self.ema_dw[0].counter,
+                        tile_noise=tile_noise)
         with torch.no_grad():
             for i in range(G):
                 self.ema_cluster_size[i].hidden.copy_(cs[i])

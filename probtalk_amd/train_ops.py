@@ -466,24 +466,38 @@ class PQQuantizeTrain(torch.autograd.Function):
         return dz, None, None
 
 
-def pq_ema_update(z, idx, cs_hidden, dw_hidden, emb, decay, eps, counter):
+def _tile_args(tile_noise, shape, need):
+    """(noise pointer tensor or None, seed) for `_tile`'s noise (vqvae_modules.py:573-577): injected N(0,1) draws in the
+    parity mode, else a seed for the kernel's own generator drawn from torch's CPU generator."""
+    if tile_noise is not None:
+        tn = tile_noise.to(device="cuda", dtype=torch.float32).contiguous()
+        if tuple(tn.shape) != tuple(shape):
+            raise RuntimeError(f"_tile noise must have shape {tuple(shape)}, got {tuple(tn.shape)}")
+        return tn, 0
+    return None, (int(torch.randint(0, 2 ** 62, (1,)).item()) if need else 0)
+
+
+def pq_ema_update(z, idx, cs_hidden, dw_hidden, emb, decay, eps, counter, tile_noise=None):
     """EMA codebook update + dead-code re-seeding (vqvae_modules.py:513-534) in place on the stacked buffers
-    cs_hidden [G,K], dw_hidden [G,K,D], emb [G,K,D]; z rows are the encoder output of this step, idx its codes."""
+    cs_hidden [G,K], dw_hidden [G,K,D], emb [G,K,D]; z rows are the encoder output of this step, idx its codes.
+    Fewer rows than codes: the seed rows are the noise-tiled batch (`_tile`); tile_noise [G,K,D] injects its N(0,1)."""
     L = _lib.lib()
     G, K, D = emb.shape
     counts, dw = _empty(G, K), _empty(G, K, D)
+    tn, seed = _tile_args(tile_noise, (G, K, D), z.shape[0] < K)
     check(L.pt_train_pq_ema(ptr(z), z.shape[1], ptr(idx), z.shape[0], G, D, K, ptr(counts), ptr(dw), ptr(cs_hidden),
-                            ptr(dw_hidden), ptr(emb), float(decay), float(eps), int(counter), stream()))
+                            ptr(dw_hidden), ptr(emb), float(decay), float(eps), int(counter), ptr(tn), seed, stream()))
 
 
-def pq_ema_update_shared(z, idx, G, cs_hidden, dw_hidden, emb, decay, eps, counter):
+def pq_ema_update_shared(z, idx, G, cs_hidden, dw_hidden, emb, decay, eps, counter, tile_noise=None):
     """share_code=True (vqvae_modules.py:496-512): the chunks of all G groups update the ONE code book in place:
     cs_hidden [K], dw_hidden [K,D], emb [K,D]; z rows [B*W, G*D], idx (B*W, G)."""
     L = _lib.lib()
     K, D = emb.shape
     counts, dw = _empty(K), _empty(K, D)
+    tn, seed = _tile_args(tile_noise, (K, D), z.shape[0] * G < K)
     check(L.pt_train_pq_ema_shared(ptr(z), z.shape[1], ptr(idx), z.shape[0], G, D, K, ptr(counts), ptr(dw), ptr(cs_hidden),
-                                   ptr(dw_hidden), ptr(emb), float(decay), float(eps), int(counter), stream()))
+                                   ptr(dw_hidden), ptr(emb), float(decay), float(eps), int(counter), ptr(tn), seed, stream()))
 
 
 def vq_ema_update(z, idx, cs_hidden, dw_hidden, emb, decay, eps, counter):

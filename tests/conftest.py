@@ -20,3 +20,11 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(params=[1, 0], ids=["split_bf16", "fp32_mfma"])
+def tap_kernel(request):
+    """Runs a test under both kernels of the fp32 tap-GEMM (option split_bf16; tests/helpers.py: tap_gemm_kernel)."""
+    from tests.helpers import tap_gemm_kernel
+    with tap_gemm_kernel(request.param) as k:
+        yield k

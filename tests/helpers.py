@@ -152,3 +152,49 @@ def share_code_case():
     xs = [(make_input(f"pqshare.x{i}", (B, C, W)) * 0.05).contiguous() for i in range(3)]
     ws = [make_input(f"pqshare.w{i}", (B, C, W)) for i in range(2)]
     return cb, xs, ws
+
+
+# ---- the fp32 tap-GEMM has two kernels (option split_bf16): the bf16-MFMA kernel with three-term operand splits (default)
+# and the fp32-MFMA kernel.  Both are fp32-accurate (tests/test_gpu_split_bf16.py), but they round differently, so in a
+# train step DIFFERENT (Leaky)ReLU units that sit within rounding of 0 land on the other side than in the oracle, and a
+# flipped unit moves its whole gradient row.  The train-step parity tests run under both kernels: the bounds of the
+# flipped case were set on the fp32-MFMA kernel's outcome and stay as they were for it; the split kernel's are the
+# module-level bounds of tests/test_gpu_module_train.py (worst tensor 5e-2 of its maximum, 1e-2 in L2 over all gradients).
+TAP_GEMM_KERNELS = [1, 0]
+TAP_GEMM_IDS = ["split_bf16", "fp32_mfma"]
+
+
+class tap_gemm_kernel:
+    def __init__(self, split):
+        self.split = split
+
+    def __enter__(self):
+        from probtalk_amd import _lib
+        _lib.check(_lib.lib().pt_set_option(b"split_bf16", self.split))
+        return self
+
+    def __exit__(self, *exc):
+        from probtalk_amd import _lib
+        _lib.check(_lib.lib().pt_set_option(b"split_bf16", 1))
+        return False
+
+    def bound(self, fp32_mfma, split_bf16):
+        return split_bf16 if self.split else fp32_mfma
+
+
+def pq_tile_case():
+    """Inputs of tests/golden/pq_tile_b8_w11.npz (tools/make_golden_pq_tile.py): batches with FEWER latent chunks than codes
+    (configs[0]'s own shape, B=8, T=88 -> 88 rows < 128 codes), so that ProductQuantization._tile (vqvae_modules.py:571-580)
+    repeats the batch and adds noise.  Per-group books: code books [G,K,D], two latent batches (8,512,11), the N(0,1) draws
+    that stand for torch.randn_like, [step][G,K,D].  share_code: one book [K,D], batches (2,512,8) (64 chunks < 128 codes),
+    draws [step][K,D]."""
+    from probtalk_amd.weights import make_input
+    C, K, G = 512, 128, 4
+    D = C // G
+    case = {"cb": (make_input("pqtile.codebook", (G, K, D)) * 0.05).contiguous(),
+            "xs": [(make_input(f"pqtile.x{i}", (8, C, 11)) * 0.05).contiguous() for i in range(2)],
+            "noise": [make_input(f"pqtile.noise{i}", (G, K, D)) for i in range(2)],
+            "cb_shared": (make_input("pqtile.codebook_shared", (K, D)) * 0.05).contiguous(),
+            "xs_shared": [(make_input(f"pqtile.xs{i}", (2, C, 8)) * 0.05).contiguous() for i in range(2)],
+            "noise_shared": [make_input(f"pqtile.noise_shared{i}", (K, D)) for i in range(2)]}
+    return case

@@ -50,7 +50,7 @@ def _cuda_params(sd):
     return out
 
 
-def test_legacy_vq_train_step_matches_oracle_and_fixture():
+def test_legacy_vq_train_step_matches_oracle_and_fixture(tap_kernel):
     sd = ref_state_dict("g")
     x = legacy_vq_train_case()
     B, _, Tn = x.shape
@@ -87,8 +87,8 @@ def test_legacy_vq_train_step_matches_oracle_and_fixture():
         den += float(gref.double().pow(2).sum())
         e = rel_err(got.cpu(), gref)
         worst = (k, e) if e > worst[1] else worst
-    assert math.sqrt(num / den) < 5e-3, math.sqrt(num / den)
-    assert worst[1] < 5e-2, worst
+    assert math.sqrt(num / den) < tap_kernel.bound(5e-3, 1e-2), math.sqrt(num / den)
+    assert worst[1] < tap_kernel.bound(5e-2, 1e-1), worst          # one flipped unit owns one row of a conv's gradient
     gold = load_gold()
     assert abs(float(loss) - float(gold["loss"])) < 2e-5 * float(gold["loss"])
     assert rel_err(pred_ncl[:, :16], gold["pred"]) < 1e-4

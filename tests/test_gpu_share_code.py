@@ -46,9 +46,11 @@ def test_share_code_train_steps_and_eval_match_reference_fixture():
     assert torch.equal(qo.quantized.cpu()[:3, 128:], g["q_eval"][:, 128:])
 
 
-def test_share_code_needs_enough_chunks_for_reseeding():
-    """rows * G < K would need the reference's noisy re-tiling (vqvae_modules.py:573-577), which is not built: loud error."""
+def test_share_code_short_batch_is_tiled_not_rejected():
+    """rows * G < K: the reference's noisy re-tiling (vqvae_modules.py:573-577) applies; parity is pinned in
+    tests/test_gpu_pq_tile.py, here only that the step runs and re-seeds dead codes from the tiled batch."""
     from probtalk_amd.nets.modules import ProductQuantization
     pq = ProductQuantization(512, 1024, 0.25, 0.99, num_chunks=4, share_code=True).cuda().train()
-    with pytest.raises(RuntimeError, match="latent rows"):
-        pq(torch.randn(2, 512, 22, device="cuda") * 0.05)
+    before = pq.embeddings_0.clone()
+    pq(torch.randn(2, 512, 22, device="cuda") * 0.05)
+    assert bool(torch.isfinite(pq.embeddings_0).all()) and not torch.equal(pq.embeddings_0, before)

@@ -351,7 +351,7 @@ def _cuda_params(sd):
     return out
 
 
-def test_predictor_train_step_matches_oracle_and_fixture():
+def test_predictor_train_step_matches_oracle_and_fixture(tap_kernel):
     sa, sp = ref_state_dict("AudEnc"), ref_state_dict("Predictor")
     aud, inp, mask, label, state, keep, ratio = train_case()
     pre, orig_relu = [], torch.relu            # the oracle's ReLU inputs (6 x linear1, then output_conv.0), recorded in order
@@ -386,7 +386,7 @@ def test_predictor_train_step_matches_oracle_and_fixture():
         assert float(po[differ].abs().max()) < 1e-5 if bool(differ.any()) else True, l
         flips += int(differ.sum())
     assert flips <= 4
-    tol = 5e-4 if flips == 0 else 3e-2
+    tol = 5e-4 if flips == 0 else tap_kernel.bound(3e-2, 5e-2)     # tests/helpers.py: tap_gemm_kernel
     worst, num, den = ("", 0.0), 0.0, 0.0
     gmax = max(float(v.abs().max()) for v in grads_o.values())
     for (tag, k), gref in grads_o.items():
@@ -402,7 +402,7 @@ def test_predictor_train_step_matches_oracle_and_fixture():
         if e > worst[1]:
             worst = (f"{tag}.{k}", e)
     assert worst[1] < tol, worst
-    assert math.sqrt(num / den) < (1e-4 if flips == 0 else 2e-3)          # all gradients as one vector
+    assert math.sqrt(num / den) < (1e-4 if flips == 0 else tap_kernel.bound(2e-3, 1e-2))          # all gradients as one vector
     # BatchNorm running statistics follow nn.BatchNorm1d
     for k, v in running_o.items():
         assert rel_err(Pa[k].cpu(), v) < 1e-5, k

@@ -59,12 +59,15 @@ def test_pq_train_quantize_ema_and_commitment(rows, counter, warm):
         assert dead > 0                       # few rows: some codes starve and are re-seeded from the first K latent rows
 
 
-def test_pq_ema_rejects_short_batches():
-    from probtalk_amd import _lib
+def test_pq_ema_short_batches_are_tiled():
+    """Fewer latent rows than codes: `_tile` (vqvae_modules.py:571-580) re-seeds dead codes from the repeated batch plus
+    noise (parity: tests/test_gpu_pq_tile.py).  All-zero rows here: every re-seeded code is pure noise * 0.01 / sqrt(D)."""
     cb = torch.zeros(4, 128, 128, device="cuda")
-    with pytest.raises(RuntimeError, match="latent rows"):
-        T.pq_ema_update(torch.zeros(64, 512, device="cuda"), torch.zeros(64, 4, dtype=torch.int64, device="cuda"),
-                        torch.zeros(4, 128, device="cuda"), torch.zeros(4, 128, 128, device="cuda"), cb, 0.99, 1e-5, 1)
+    noise = torch.randn(4, 128, 128)
+    T.pq_ema_update(torch.zeros(64, 512, device="cuda"), torch.zeros(64, 4, dtype=torch.int64, device="cuda"),
+                    torch.zeros(4, 128, device="cuda"), torch.zeros(4, 128, 128, device="cuda"), cb, 0.99, 1e-5, 1, tile_noise=noise)
+    std = torch.tensor(0.01 / 128 ** 0.5, dtype=torch.float32)
+    assert torch.equal(cb[:, 1:].cpu(), (noise * std)[:, 1:])          # code 0 took all 64 rows, codes 1.. are dead
 
 
 @pytest.mark.parametrize("B,Tn", [(3, 16), (2, 88)])

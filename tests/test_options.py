@@ -19,6 +19,7 @@ OPTIONS = {
     "store_overlap": (1, 0, (-1, 2)),
     "row2": (0, 1, (-1, 2)),
     "row2_min_rows": (20480, 1, (-1,)),
+    "split_bf16": (1, 0, (-1, 2)),
 }
 
 
