@@ -537,7 +537,8 @@ __global__ __launch_bounds__(256) void attn_fwd_train_kernel(const float* __rest
 //   "mix" C[m][n] = sum_k A[m][k] B[k][n]   (O = Pd V, dQ = dS K)
 // fp32 MFMA has the same peak as the fp32 vector unit on gfx950 (157 TFLOP/s), so the vector FMAs cost nothing here and
 // keep the summation free of layout shuffles.  LDS need at Nq = Nk = 88 (the predictor's 22 x 4 tokens): 158 KB of the
-// 160 KB, one workgroup per CU.  Shapes that do not fit fall back to the one-wave-per-row kernels above.
+// 160 KB, one workgroup per CU.  Longer sequences take the query-blocked variants below (K and V resident, up to 212 keys in
+// the backward pass); what fits neither falls back to the one-wave-per-row kernels above.
 // The dropout mask index is the same ((b*H+h)*Nq+i)*Nk+j as in those kernels.
 // ---------------------------------------------------------------------------
 constexpr int AT = 512;
@@ -769,6 +770,199 @@ __global__ __launch_bounds__(AT) void attn_bwd_tiled_kernel(const float* __restr
   }
 }
 
+// ---- query-blocked variants (round 3): K and V of a (clip, head) stay in LDS, the queries pass through in blocks, so the
+// refiner's 180-frame train step (Nq = Nk = 180: K + V = 92 KB) no longer falls back to the one-wave-per-row kernels.
+// Forward: grid (clip x head, query block), 64 queries per block.  Backward: ONE workgroup per (clip, head) walks the
+// query blocks (32 queries each), writes dQ block by block and keeps its dK / dV tiles in registers across the blocks:
+// no atomics, the summation order over queries is fixed.  Same tile routines, same dropout mask index as above.
+constexpr int AT_QF = 64, AT_QB = 32;
+
+__global__ __launch_bounds__(AT) void attn_fwd_qblock_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
+                                                             int ldk, const float* __restrict__ V, int ldv, float* __restrict__ O,
+                                                             int ldo, int Nq, int Nk, int H, float scale, float pdrop,
+                                                             unsigned long long seed) {
+  extern __shared__ __attribute__((aligned(16))) float at_sm[];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int q0 = blockIdx.y * AT_QF;
+  const int nq = min(AT_QF, Nq - q0);                 // live queries of this block
+  const int NQ4 = at_ru4(nq), NK4 = at_ru4(Nk), pp = at_pitch(Nk);
+  float* Qs = at_sm;                  // [AT_QF][68]
+  float* Ks = Qs + AT_QF * 68;        // [NK4][64]
+  float* Vs = Ks + NK4 * 64;          // [NK4][64]
+  float* Ps = Vs + NK4 * 64;          // [AT_QF][pp]
+  at_load_rows(Qs, 68, Q + (size_t)(b * Nq + q0) * ldq + h * 64, ldq, nq, NQ4);
+  at_load_rows(Ks, 64, K + (size_t)b * Nk * ldk + h * 64, ldk, Nk, NK4);
+  at_load_rows(Vs, 64, V + (size_t)b * Nk * ldv + h * 64, ldv, Nk, NK4);
+  __syncthreads();
+  const int TM = NQ4 / 4, TN = NK4 / 4;
+  for (int t = threadIdx.x; t < TM * TN; t += AT) {
+    const int mi = t % TM, n0 = (t / TM) * 4;
+    float acc[4][4] = {};
+    at_kc(Qs, 68, Ks, 64, mi, TM, n0, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<float4*>(Ps + (mi + r * TM) * pp + n0) =
+          make_float4(acc[r][0] * scale, acc[r][1] * scale, acc[r][2] * scale, acc[r][3] * scale);
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned thr = (unsigned)((double)pdrop * 4294967296.0);
+  const float ks = 1.f / (1.f - pdrop);
+  for (int i = wave; i < NQ4; i += AT / 64) {
+    float* row = Ps + i * pp;
+    if (i >= nq) {
+      for (int j = lane; j < NK4; j += 64) row[j] = 0.f;
+      continue;
+    }
+    float mx = -INFINITY;
+    for (int j = lane; j < Nk; j += 64) mx = fmaxf(mx, row[j]);
+    mx = wmax(mx);
+    float l = 0.f;
+    for (int j = lane; j < Nk; j += 64) l += expf(row[j] - mx);
+    l = wsum(l);
+    const size_t mbase = ((size_t)(b * H + h) * Nq + q0 + i) * Nk;
+    for (int j = lane; j < NK4; j += 64) {
+      float pj = 0.f;
+      if (j < Nk) {
+        pj = expf(row[j] - mx) / l;
+        if (pdrop > 0.f) pj *= attn_keep(seed, mbase + j, thr, ks);
+      }
+      row[j] = pj;
+    }
+  }
+  __syncthreads();
+  float* Ob = O + (size_t)(b * Nq + q0) * ldo + h * 64;
+  for (int t = threadIdx.x; t < TM * 16; t += AT) {
+    const int n0 = (t & 15) * 4, m0 = (t >> 4) * 4;
+    float acc[4][4] = {};
+    at_mix(Ps, pp, Vs, 64, NK4, m0, n0, acc);
+    at_store_rows(Ob, ldo, m0, n0, nq, acc);
+  }
+}
+
+// JMAX = ceil(Nk / 64) score columns per lane; KT = dK / dV tiles (4 keys x 4 columns) per thread: ceil(Nk/4 * 16 / AT)
+template <int JMAX, int KT>
+__global__ __launch_bounds__(AT) void attn_bwd_qblock_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
+                                                             int ldk, const float* __restrict__ V, int ldv,
+                                                             const float* __restrict__ dO, int ldo, float* __restrict__ dQ,
+                                                             int lddq, float* __restrict__ dK, int lddk, float* __restrict__ dV,
+                                                             int lddv, int Nq, int Nk, int H, float scale, float pdrop,
+                                                             unsigned long long seed) {
+  extern __shared__ __attribute__((aligned(16))) float at_sm[];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int NK4 = at_ru4(Nk), pp = at_pitch(Nk), TN = NK4 / 4;
+  float* Qs = at_sm;                  // [AT_QB][68]
+  float* Gs = Qs + AT_QB * 68;        // dO [AT_QB][68]
+  float* Ks = Gs + AT_QB * 68;        // [NK4][64]
+  float* Vs = Ks + NK4 * 64;          // [NK4][64]
+  float* Ps = Vs + NK4 * 64;          // S, then Pd = P * keep        [AT_QB][pp]
+  float* Ds = Ps + AT_QB * pp;        // dPd, then dS                 [AT_QB][pp]
+  at_load_rows(Ks, 64, K + (size_t)b * Nk * ldk + h * 64, ldk, Nk, NK4);
+  at_load_rows(Vs, 64, V + (size_t)b * Nk * ldv + h * 64, ldv, Nk, NK4);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned thr = (unsigned)((double)pdrop * 4294967296.0);
+  const float ks = 1.f / (1.f - pdrop);
+  const int nkv = TN * 16;            // dK / dV tiles of this head
+  float av[KT][4][4] = {}, ak[KT][4][4] = {};
+  for (int q0 = 0; q0 < Nq; q0 += AT_QB) {
+    const int nq = min(AT_QB, Nq - q0), NQ4 = at_ru4(nq), TM = NQ4 / 4;
+    __syncthreads();                  // the previous block's tiles are read (and K / V have landed, first time round)
+    at_load_rows(Qs, 68, Q + (size_t)(b * Nq + q0) * ldq + h * 64, ldq, nq, NQ4);
+    at_load_rows(Gs, 68, dO + (size_t)(b * Nq + q0) * ldo + h * 64, ldo, nq, NQ4);
+    __syncthreads();
+    for (int t = threadIdx.x; t < TM * TN; t += AT) {
+      const int mi = t % TM, n0 = (t / TM) * 4;
+      float acc[4][4] = {}, acd[4][4] = {};
+      at_kc(Qs, 68, Ks, 64, mi, TM, n0, acc);
+      at_kc(Gs, 68, Vs, 64, mi, TM, n0, acd);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        *reinterpret_cast<float4*>(Ps + (mi + r * TM) * pp + n0) =
+            make_float4(acc[r][0] * scale, acc[r][1] * scale, acc[r][2] * scale, acc[r][3] * scale);
+        *reinterpret_cast<float4*>(Ds + (mi + r * TM) * pp + n0) = make_float4(acd[r][0], acd[r][1], acd[r][2], acd[r][3]);
+      }
+    }
+    __syncthreads();
+    for (int i = wave; i < NQ4; i += AT / 64) {
+      float* prow = Ps + i * pp;
+      float* drow = Ds + i * pp;
+      if (i >= nq) {
+        for (int j = lane; j < NK4; j += 64) { prow[j] = 0.f; drow[j] = 0.f; }
+        continue;
+      }
+      float sv[JMAX], mx = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < JMAX; ++u) {
+        const int j = lane + 64 * u;
+        sv[u] = j < Nk ? prow[j] : -INFINITY;
+        mx = fmaxf(mx, sv[u]);
+      }
+      mx = wmax(mx);
+      float l = 0.f;
+#pragma unroll
+      for (int u = 0; u < JMAX; ++u) {
+        sv[u] = (lane + 64 * u) < Nk ? expf(sv[u] - mx) : 0.f;
+        l += sv[u];
+      }
+      l = wsum(l);
+      const size_t mbase = ((size_t)(b * H + h) * Nq + q0 + i) * Nk;
+      float kp[JMAX], dp[JMAX], dl = 0.f;
+#pragma unroll
+      for (int u = 0; u < JMAX; ++u) {
+        const int j = lane + 64 * u;
+        sv[u] = sv[u] / l;                                        // P
+        kp[u] = (pdrop > 0.f && j < Nk) ? attn_keep(seed, mbase + j, thr, ks) : 1.f;
+        dp[u] = j < Nk ? drow[j] * kp[u] : 0.f;                   // dP = dPd * keep
+        dl += sv[u] * dp[u];
+      }
+      dl = wsum(dl);
+#pragma unroll
+      for (int u = 0; u < JMAX; ++u) {
+        const int j = lane + 64 * u;
+        if (j < NK4) {
+          prow[j] = j < Nk ? sv[u] * kp[u] : 0.f;                 // Pd
+          drow[j] = j < Nk ? sv[u] * (dp[u] - dl) * scale : 0.f;  // dS (scale folded)
+        }
+      }
+    }
+    __syncthreads();
+    // dQ of this block, and this block's share of dK / dV into the thread's register tiles
+    float* dQb = dQ + (size_t)(b * Nq + q0) * lddq + h * 64;
+    for (int t = threadIdx.x; t < TM * 16; t += AT) {
+      const int n0 = (t & 15) * 4, m0 = (t >> 4) * 4;
+      float aq[4][4] = {};
+      at_mix(Ds, pp, Ks, 64, NK4, m0, n0, aq);                    // dQ = dS K
+      at_store_rows(dQb, lddq, m0, n0, nq, aq);
+    }
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+      const int t = threadIdx.x + u * AT;
+      if (t < nkv) {
+        const int n0 = (t & 15) * 4, m0 = (t >> 4) * 4;
+        at_km(Ps, pp, Gs, 68, nq, m0, n0, av[u]);                 // dV += Pd^T dO
+        at_km(Ds, pp, Qs, 68, nq, m0, n0, ak[u]);                 // dK += dS^T Q
+      }
+    }
+  }
+  float* dKb = dK + (size_t)b * Nk * lddk + h * 64;
+  float* dVb = dV + (size_t)b * Nk * lddv + h * 64;
+#pragma unroll
+  for (int u = 0; u < KT; ++u) {
+    const int t = threadIdx.x + u * AT;
+    if (t < nkv) {
+      const int n0 = (t & 15) * 4, m0 = (t >> 4) * 4;
+      at_store_rows(dVb, lddv, m0, n0, Nk, av[u]);
+      at_store_rows(dKb, lddk, m0, n0, Nk, ak[u]);
+    }
+  }
+}
+
+static size_t at_qblock_lds_bytes(int Nk, bool bwd) {
+  const size_t k = (size_t)at_ru4(Nk) * 64;
+  const int qb = bwd ? AT_QB : AT_QF;
+  return 4 * ((bwd ? 2 : 1) * (size_t)qb * 68 + 2 * k + (bwd ? 2 : 1) * (size_t)qb * at_pitch(Nk));
+}
+
 static size_t at_lds_bytes(int Nq, int Nk, bool bwd) {
   const size_t q = (size_t)at_ru4(Nq) * 68, k = (size_t)at_ru4(Nk) * 64, p = (size_t)at_ru4(Nq) * at_pitch(Nk);
   return 4 * (bwd ? 2 * q + 2 * k + 2 * p : q + 2 * k + p);
@@ -783,6 +977,13 @@ int launch_attention_train_fwd(const float* Q, int ldq, const float* K, int ldk,
     PT_ENSURE_LDS(attn_fwd_tiled_kernel, 160 * 1024);
     PT_LAUNCH(attn_fwd_tiled_kernel, dim3(B * H), dim3(AT), at_lds_bytes(Nq, Nk, false), s, Q, ldq, K, ldk, V, ldv, O, ldo, Nq,
               Nk, H, 0.125f, pdrop, seed);
+    return 0;
+  }
+  if (at_qblock_lds_bytes(Nk, false) <= 160 * 1024 && at_aligned(Q, ldq) && at_aligned(K, ldk) && at_aligned(V, ldv) &&
+      at_aligned(O, ldo) && option(OPT_ATTN_TRAIN_ROWWISE) == 0) {
+    PT_ENSURE_LDS(attn_fwd_qblock_kernel, 160 * 1024);
+    PT_LAUNCH(attn_fwd_qblock_kernel, dim3(B * H, (Nq + AT_QF - 1) / AT_QF), dim3(AT), at_qblock_lds_bytes(Nk, false), s, Q, ldq, K,
+              ldk, V, ldv, O, ldo, Nq, Nk, H, 0.125f, pdrop, seed);
     return 0;
   }
   PT_CHECK(Nk <= 4096, "attention_train_fwd: %d keys exceed the per-wave score buffer", Nk);
@@ -800,6 +1001,15 @@ int launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const
     PT_ENSURE_LDS(attn_bwd_tiled_kernel<2>, 160 * 1024);
     PT_LAUNCH(attn_bwd_tiled_kernel<2>, dim3(B * H), dim3(AT), at_lds_bytes(Nq, Nk, true), s, Q, ldq, K, ldk, V, ldv, dO, ldo, dQ,
               lddq, dK, lddk, dV, lddv, Nq, Nk, H, 0.125f, pdrop, seed);
+    return 0;
+  }
+  if (at_qblock_lds_bytes(Nk, true) <= 160 * 1024 && Nk <= 256 && at_aligned(Q, ldq) && at_aligned(K, ldk) && at_aligned(V, ldv) &&
+      at_aligned(dO, ldo) && at_aligned(dQ, lddq) && at_aligned(dK, lddk) && at_aligned(dV, lddv) &&
+      option(OPT_ATTN_TRAIN_ROWWISE) == 0) {
+    // Nk <= 256: four score columns per lane, at most 1,024 dK / dV tiles = two per thread
+    PT_ENSURE_LDS((attn_bwd_qblock_kernel<4, 2>), 160 * 1024);
+    PT_LAUNCH((attn_bwd_qblock_kernel<4, 2>), dim3(B * H), dim3(AT), at_qblock_lds_bytes(Nk, true), s, Q, ldq, K, ldk, V, ldv, dO, ldo,
+              dQ, lddq, dK, lddk, dV, lddv, Nq, Nk, H, 0.125f, pdrop, seed);
     return 0;
   }
   PT_CHECK(Nk <= 2048, "attention_bwd: %d keys exceed the per-wave score buffer", Nk);

@@ -134,7 +134,7 @@ def _mha(q, k, v, B, Nq, Nk):
     return (a @ vh).transpose(1, 2).reshape(B * Nq, 512)
 
 
-@pytest.mark.parametrize("B,N", [(3, 44), (2, 100), (1, 7)])
+@pytest.mark.parametrize("B,N", [(3, 44), (2, 100), (1, 7), (2, 180), (1, 212), (1, 300)])   # 97..212 keys: query-blocked kernels
 def test_attention_self(B, N):
     g = torch.Generator().manual_seed(N)
     qkv = torch.randn(B * N, 1536, generator=g)
@@ -149,7 +149,7 @@ def test_attention_self(B, N):
     assert rel_err(d.grad.cpu(), r.grad) < TOL
 
 
-@pytest.mark.parametrize("B,Nq,Nk", [(2, 44, 11), (2, 100, 25), (1, 5, 3)])
+@pytest.mark.parametrize("B,Nq,Nk", [(2, 44, 11), (2, 100, 25), (1, 5, 3), (2, 300, 37), (1, 130, 180)])
 def test_attention_cross(B, Nq, Nk):
     g = torch.Generator().manual_seed(Nq)
     q, kv = torch.randn(B * Nq, 512, generator=g), torch.randn(B * Nk, 1024, generator=g)
@@ -192,11 +192,13 @@ def test_attention_dropout_replay_and_scale():
     assert abs(lhs - rhs) < 1e-4 * abs(lhs)
 
 
-@pytest.mark.parametrize("B,Nq,Nk,p", [(3, 88, 88, 0.1), (2, 88, 22, 0.1), (1, 7, 3, 0.25), (2, 100, 100, 0.0), (1, 130, 40, 0.1)])
+@pytest.mark.parametrize("B,Nq,Nk,p", [(3, 88, 88, 0.1), (2, 88, 22, 0.1), (1, 7, 3, 0.25), (2, 100, 100, 0.0), (1, 130, 40, 0.1),
+                                       (2, 180, 180, 0.1), (1, 97, 212, 0.1), (2, 300, 37, 0.1), (1, 300, 300, 0.1)])
 def test_attention_tiled_matches_rowwise(B, Nq, Nk, p):
     """The LDS-tiled (clip, head) kernels and the one-wave-per-row fallback share the dropout mask indexing: same
-    outputs and gradients for the same seed.  (100x100 and 130x40 exceed the LDS budget / key bound: both runs take the
-    fallback there, which checks the dispatch.)"""
+    outputs and gradients for the same seed.  100x100 .. 97x212 and 300x37 take the query-blocked kernels (K and V
+    resident, queries in blocks), 300x300 exceeds their LDS budget: both runs take the fallback there, which checks the
+    dispatch."""
     g = torch.Generator().manual_seed(Nq + Nk)
     q, kv = torch.randn(B * Nq, 512, generator=g).cuda(), torch.randn(B * Nk, 1024, generator=g).cuda()
     do = torch.randn(B * Nq, 512, generator=g).cuda()
