@@ -5,6 +5,9 @@ import torch
 from probtalk_amd import _lib
 
 L = _lib.lib()
+for kv in os.environ.get("PT_OPTIONS", "").split(","):       # e.g. PT_OPTIONS=gemm8_krot=1,store_overlap=0
+    if kv:
+        _lib.check(L.pt_set_option(kv.split("=")[0].encode(), int(kv.split("=")[1])))
 shapes = [(9472, 512, 512), (9472, 1536, 512), (9472, 2048, 512), (9472, 512, 2048), (9472, 128, 512),
           (75776, 512, 512), (75776, 1536, 512), (75776, 2048, 512), (75776, 512, 2048), (75776, 128, 512),
           (153600, 512, 512), (153600, 1536, 512), (153600, 2048, 512), (153600, 512, 2048), (153600, 376, 1024),
