@@ -178,7 +178,7 @@ int pt_model_finalize(pt_model* h) {
   if (finalize_model(h->m)) return 1;
   // set-up time, current device: the code search's dynamic-LDS attribute, so that pt_pq_quantize_static itself makes no
   // runtime query (it may run under stream capture)
-  if (h->scratch && pq_search_prepare(h->m.vq.emb_dim / h->m.vq.groups)) return 1;
+  if (h->scratch && pq_search_prepare(h->m.vq.emb_dim / h->m.vq.groups, h->m.vq.num_codes)) return 1;
   return 0;
 }
 

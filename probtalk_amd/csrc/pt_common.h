@@ -183,7 +183,7 @@ int launch_postprocess(const float* pred, int B, int T, const float* mean, const
 // prepared = true: pq_search_prepare(D) has run on this device (model finalize), no attribute call here
 int launch_pq_search(const float* z_cl, int ldz, const float* codebooks, int rows, int G, int D, int K,
                      int64_t* idx, float* q_cl, int ldq, hipStream_t s, bool prepared = false);
-int pq_search_prepare(int D);
+int pq_search_prepare(int D, int K);
 int launch_pq_gather(const void* idx, int idx_is_i64, const float* codebooks, int rows, int G, int D, int K,
                      float* q_cl, int ldq, int zero_to, hipStream_t s);
 

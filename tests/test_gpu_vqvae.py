@@ -216,3 +216,38 @@ def test_condition_encoder():
     assert rel_err(out.cpu(), g["audio"]) < TOL
     aud2 = make_input("pred.aud300", (3, 768, 300))
     assert rel_err(m(aud2.cuda()).cpu(), O.condition_encoder(sd, aud2)) < TOL
+
+
+def test_pq_search_resident_kernel_equals_staging_kernel():
+    """Large batches take the kernel that keeps a whole sub-codebook in LDS and walks the row tiles (layout_pq.hip);
+    batches of fewer than 2 x #CUs tile units take the staging kernel.  Same arithmetic to the bit: the indices and the
+    gathered code rows of one 18,944-row call (512 clips x 37 latent steps, ragged last tile included) equal those of
+    the same rows searched in 4,096-row pieces."""
+    from probtalk_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(77)
+    rows, G, K, D = 18944 + 37, 4, 128, 128
+    z = torch.randn(rows, G * D, generator=g).cuda()
+    cb = (torch.randn(G, K, D, generator=g) * 0.7).cuda().contiguous()
+    z[5] = z[4]                                         # a duplicated row: ties inside the batch change nothing
+    cb[1, 77] = cb[1, 3]                                # a duplicated code: lowest index must win in both kernels
+    idx = torch.full((rows, G), -1, dtype=torch.int64, device="cuda")
+    q = torch.full((rows, G * D), float("nan"), device="cuda")
+    _lib.check(lib.pt_pq_search_cl(_lib.ptr(z), G * D, _lib.ptr(cb), rows, G, D, K, _lib.ptr(idx), _lib.ptr(q), G * D, _lib.stream()))
+    idx2 = torch.full((rows, G), -1, dtype=torch.int64, device="cuda")
+    q2 = torch.full((rows, G * D), float("nan"), device="cuda")
+    for r0 in range(0, rows, 4096):
+        n = min(4096, rows - r0)
+        zs, is_, qs = z[r0:r0 + n], idx2[r0:r0 + n], q2[r0:r0 + n]
+        _lib.check(lib.pt_pq_search_cl(_lib.ptr(zs), G * D, _lib.ptr(cb), n, G, D, K, _lib.ptr(is_), _lib.ptr(qs), G * D, _lib.stream()))
+    torch.cuda.synchronize()
+    assert int(idx.min()) >= 0 and int(idx.max()) < K
+    assert torch.equal(idx, idx2) and torch.equal(q, q2)
+    assert not bool((idx[:, 1] == 77).any()), "a duplicated code must lose to its lower-index twin"
+    # and against plain torch on the same operands (near-ties aside)
+    d = ((z.view(rows, G, D).double().unsqueeze(2) - cb.double().unsqueeze(0)) ** 2).sum(-1)       # (rows, G, K)
+    ref = d.argmin(-1)
+    mism = ref != idx
+    if int(mism.sum()):
+        top2 = d.topk(2, dim=-1, largest=False).values
+        assert float((top2[..., 1] - top2[..., 0])[mism].max()) < 1e-5 * float((z ** 2).sum(-1).mean())
