@@ -29,7 +29,11 @@
 //     phases), 20.7 ms this way;
 //   * every other tile (edges, fp32 / positional / residual epilogues, the last tile of a workgroup) ends with vmcnt(0)
 //     BEFORE its stores.
-// Either way the next tile's first K-tile issues no waits (everything it reads has landed by then).
+// Either way everything the next tile's first K-tile reads has landed by then.  After a vmcnt(0) that K-tile issues no
+// waits; after an early tile its P3 / P4 retire the two half-tiles still in flight behind the stores (vmcnt(24) / (20)).
+// The bias row sits in LDS (written once per workgroup): accumulators start at the bias, and a bias read from memory at the
+// head of every tile made the compiler wait for vmcnt(0) there, i.e. for every store of the tile before and every DMA in
+// flight (round 3, profiles/r3/tile_head_bias_loads.txt).
 #include <cstdlib>
 
 #include "pt_common.h"
@@ -50,7 +54,9 @@ bool prof_is_on();
 
 constexpr int G8_HT = 128 * 128;          // bytes of a half-tile image (128 rows x 64 bf16)
 constexpr int G8_STAGE = 4 * G8_HT;       // one K-tile buffer
-constexpr int G8_SMEM = 2 * G8_STAGE;
+constexpr int G8_RING = 2 * G8_STAGE;
+constexpr int G8_BIAS_COLS = 8192;        // bias row kept in LDS (fp32): columns of the widest launch that uses it
+constexpr int G8_SMEM = G8_RING + G8_BIAS_COLS * 4;
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -118,7 +124,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
   }
   // prologue: K-tile 0 whole, then h0 / h2 of K-tile 1 (the loop issues h3 / h1 of t+1 and h0 / h2 of t+2)
   issue(0); issue(2); issue(3); issue(1); issue(0); issue(2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float* bias_s = reinterpret_cast<float*>(smem + G8_RING);
+  for (int n = tid * 4; n < tiles_n * 256; n += 2048) {
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);      // N % 8 == 0 (launcher)
+    *reinterpret_cast<f32x4*>(bias_s + n) = bv;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();                    // waves 4-7 run one barrier behind
 
@@ -132,6 +144,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
   bf16x8 af[4][2], bfr[2][2][2];
   int cbuf = 0;
 
+  bool after_early = false;
   for (int tile = tile0; tile < ntiles; tile += G) {
     {
       // accumulators start at the bias (its loads overlap the first K-tile instead of standing in the epilogue)
@@ -141,8 +154,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n = tn0 * 256 + wc * 64 + j * 16 + 4 * iq;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + n);
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i][j] = bv;
       }
@@ -197,11 +209,20 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
       };
       // `stores` = early store instructions of this K-tile already in the queue: they are younger than the half-tile
       // this wait retires, so the count grows by them and the DMA retires exactly where it does without them
-      auto wait = [&](int stores) {
+      // First K-tile of a tile: after the prologue or a tile that ended with vmcnt(0) nothing is pending.  After an
+      // `early` tile the half-tiles that tile issued in its last P3 / P4 (this tile's K-tile 1, h0 / h2) are still in
+      // flight behind its stores; they are read in P1 of K-tile 1, so P3 / P4 here retire them as every other K-tile's
+      // P3 / P4 would: younger than the P3 half-tile are 4 + 8 stores, the P4 half-tile and its 4 stores and this tile's
+      // three half-tiles so far = 24 instructions; younger than the P4 half-tile 4 + 8 stores and four half-tiles = 20.
+      auto wait = [&](int stores, int first = -1) {
         if (t > 0) {
           if (draining) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           else if (fl && stores == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else if (after_early && first >= 0) {
+          if (draining) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else if (first == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
         }
       };
       auto mma = [&](int mh, int nh) {
@@ -227,11 +248,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
       readB(1); issue(1); wait(0);
       mma(0, 1);
       // P3
-      readA(1); issue(0); wait(0);
+      readA(1); issue(0); wait(0, 24);
       if (fl) storeRows(0, 0, 2);
       mma(1, 1);
       // P4
-      issue(2); wait(4);
+      issue(2); wait(4, 20);
       if (fl) storeRows(0, 2, 2);
       mma(1, 0);
     }
@@ -240,6 +261,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
       // than it: 16 stores and the two half-tiles of P3 / P4 = 20 instructions
       storeRows(1, 0, 4);
       asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      after_early = true;
       continue;
     }
 
@@ -276,6 +298,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmBigArgs p, const i
     }
     // everything staged so far has landed before the stores join the vmcnt queue (see the header)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    after_early = false;
     // fp32 rows leave straight from the accumulators (16 rows x 64 B per instruction); bf16: accumulators j and j+1
     // exchange 16-lane rows (v_permlane16_swap), then a lane holds 8 consecutive bf16 columns
 #pragma unroll

@@ -33,7 +33,9 @@ bool prof_is_on();
 
 constexpr int C8_HT = 128 * 128;          // bytes of a half-tile image (128 rows x 64 bf16)
 constexpr int C8_STAGE = 4 * C8_HT;
-constexpr int C8_SMEM = 2 * C8_STAGE;
+constexpr int C8_RING = 2 * C8_STAGE;
+constexpr int C8_BIAS_COLS = 4096;        // bias row kept in LDS (fp32), see gemm_bf16_8ph.hip
+constexpr int C8_SMEM = C8_RING + C8_BIAS_COLS * 4;
 
 __device__ __forceinline__ unsigned c8_pack(float a, float b) {
   bf16x2 v = {(__bf16)a, (__bf16)b};
@@ -128,7 +130,13 @@ __global__ __launch_bounds__(512) void conv8_kernel(const GemmArgsB p, const uns
   }
   // prologue: K-tile 0 whole, then h0 / h2 of K-tile 1 (the loop issues h3 / h1 of t+1 and h0 / h2 of t+2)
   issue(0); issue(2); issue(3); issue(1); issue(0); issue(2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float* bias_s = reinterpret_cast<float*>(smem + C8_RING);
+  for (int n = tid * 4; n < tiles_n * 256; n += 2048) {
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);      // N % 8 == 0 (conv8_takes)
+    *reinterpret_cast<f32x4*>(bias_s + n) = bv;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();                    // waves 4-7 run one barrier behind
 
@@ -150,8 +158,7 @@ __global__ __launch_bounds__(512) void conv8_kernel(const GemmArgsB p, const uns
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n = tn0 * 256 + wc * 64 + j * 16 + 4 * iq;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + n);
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i][j] = bv;
       }
@@ -363,7 +370,7 @@ bool conv8_takes(const GemmArgsB& a) {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !c8_zero[dev]) return false;
   if (a.pe || a.Res) return false;
   if (a.act == ACT_GATED && (a.N % 64 != 0 || a.ResB)) return false;
-  if (a.K % 64 != 0 || a.K * a.ntaps < 128 || a.N % 8 != 0 || a.N < 192) return false;
+  if (a.K % 64 != 0 || a.K * a.ntaps < 128 || a.N % 8 != 0 || a.N < 192 || a.N > C8_BIAS_COLS) return false;
   if (a.zero_to % 8 != 0 || (a.Cb && (a.ldcb % 8 != 0 || ((uintptr_t)a.Cb & 15))) || (a.C && (a.ldc % 4 != 0 || ((uintptr_t)a.C & 15))))
     return false;
   if (a.ResB && (a.ldr % 4 != 0 || ((uintptr_t)a.ResB & 7))) return false;

@@ -42,7 +42,8 @@ constexpr int GR_STAGE = GR_AMAX + 32768;          // [A | B-lo | B-hi]
 constexpr int GR_RED = 3 * GR_STAGE;               // LayerNorm partial sums: [2][8 waves][160 rows] floats
 constexpr int GR_TAB = GR_RED + 2 * 8 * 160 * 4;   // LayerNorm affine tables: [classes][gamma' 512 | beta' 512] floats, 4 classes at most
 constexpr int GR_TAB_CLASSES = 4;
-constexpr int GR_SMEM = GR_TAB + GR_TAB_CLASSES * 4096;
+constexpr int GR_BIAS = GR_TAB + GR_TAB_CLASSES * 4096;   // the Linear's bias row (512 floats)
+constexpr int GR_SMEM = GR_BIAS + 2048;
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   bf16x2 v = {(__bf16)a, (__bf16)b};
@@ -135,12 +136,16 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
     if (tid < 128) *reinterpret_cast<f32x4*>(tab + 4 * tid) = *reinterpret_cast<const f32x4*>(p.gamma + 4 * tid);
     else if (tid < 256) *reinterpret_cast<f32x4*>(tab + 4 * tid) = *reinterpret_cast<const f32x4*>(p.beta + 4 * (tid - 128));
   }
+  // ... and the bias row: read from memory at the head of every tile it made the compiler wait for vmcnt(0) before the
+  // tile's first MFMA, i.e. for every store of the tile before (round 3, profiles/r3/tile_head_bias_loads.txt)
+  float* bias_s = reinterpret_cast<float*>(smem + GR_BIAS);
+  if (tid < 128) *reinterpret_cast<f32x4*>(bias_s + 4 * tid) = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + 4 * tid) : f32x4{0.f, 0.f, 0.f, 0.f};
   c_tile[0] = c_tile[1] = tile0;
   c_kt[0] = c_kt[1] = 0;
   c_buf[0] = c_buf[1] = 0;
   set_srcA(tile0);
   issue_p1(); issue_p2(); issue_p1(); issue_p2();                // K-tiles 0 and 1
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();                    // waves 4-7 run one barrier behind
 
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(512) void gemm_row_kernel(const GemmBigArgs p, cons
       const int nb = wave * 64 + 4 * iq;
       f32x4 bv[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bv[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const f32x4*>(bias_s + nb + j * 16);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int m = tile * BM + i * 16 + ir;
