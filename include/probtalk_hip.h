@@ -323,8 +323,9 @@ int pt_postprocess_poses(const float* pred, int B, int T, const float* mean, con
  *                        measured 8-30 % slower per launch)
  *   "row2_min_rows"      rows from which row2 applies (default 20480 = 80 rows x 256 CUs)
  *   "split_bf16"         1 (default) the fp32 tap-GEMM (fp32 mode, PQ-VAE encoder, training forward / input gradients)
- *                        runs on the bf16 matrix cores with each fp32 operand split into three bf16 terms and six
- *                        products per pair (fp32 accuracy at 2.7 x the fp32 MFMA rate); 0 = the fp32 MFMA kernel
+ *                        and the weight gradient (pt_train_wgrad) run on the bf16 matrix cores with each fp32 operand
+ *                        split into three bf16 terms and six products per pair (fp32 accuracy at 2.7 x the fp32 MFMA
+ *                        rate); 0 = the fp32 MFMA kernels
  * Unknown names and out-of-range values are errors (non-zero return, pt_last_error). */
 int pt_set_option(const char* name, int value);
 int pt_get_option(const char* name, int* value);

@@ -163,7 +163,7 @@ enum Option {
   OPT_STORE_OVERLAP,       // 1 (default): the 256 x 256 GEMM stores a tile's upper half between the phases of its last K-tile
   OPT_ROW2,                // 1: N = 512 Linears with at least row2_min_rows rows run two 80-row workgroups per CU (gemm_bf16_row2.hip); default 0 (measured slower)
   OPT_ROW2_MIN_ROWS,       // rows from which the two-workgroups-per-CU row kernel is used (default 20480 = 80 rows x 256 CUs)
-  OPT_SPLIT_BF16,          // 1 (default): fp32 tap-GEMMs (fp32 mode, PQ-VAE encoder, train step) run on the bf16 MFMA with both
+  OPT_SPLIT_BF16,          // 1 (default): fp32 tap-GEMMs and weight gradients (fp32 mode, PQ-VAE encoder, train step) run on the bf16 MFMA with both
                            // operands split into three bf16 terms, six products (fp32 accuracy, 2.7 x the fp32 MFMA rate); 0: fp32 MFMA
   OPT_COUNT
 };

@@ -138,6 +138,179 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, int tiles
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same weight gradient on the bf16 MFMA at fp32 accuracy (round 3; option split_bf16, as the forward tap-GEMM in
+// gemm.hip: each fp32 operand = three bf16 terms, six products, smallest first).  The contraction index is the GEMM row m,
+// which is the STRIDED index of both operands in memory, while a v_mfma_f32_32x32x16_bf16 lane wants 8 consecutive k.
+// The transposition happens in registers: a thread loads a 4 (m) x 4 (columns) patch of each operand (four float4), so it
+// holds 4 consecutive m for each of its 4 columns and writes them as 8-byte k-runs into the [column][k] LDS planes the
+// forward kernel uses (80-byte rows, three planes per operand, 60 KB: two workgroups per CU).  Lanes 0-7 of every 8 are
+// the eight 4-row groups of a K-step of 32 rows, so the 8-byte writes of one column row are contiguous (a wave's write
+// instruction is 8 column rows x 64 bytes, 320 bytes apart: 4 lanes per bank, the 4 cycles that 512 bytes cost anyway).
+// Workgroup = 128 (n) x 128 (c) tile of one tap over one slice of m, 4 waves 2 x 2, fp32 atomics across slices; global
+// loads run two K-steps ahead in two register sets.
+// ---------------------------------------------------------------------------
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int wg_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int WG_ROW = 80, WG_PLANE = 256 * WG_ROW, WG_SMEM = 3 * WG_PLANE;
+
+__device__ __forceinline__ void wg_split3(const f32x4 v, wg_u32x2& h, wg_u32x2& m, wg_u32x2& l) {
+  const wg_bf16x4 b0 = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  f32x4 r1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r1[e] = v[e] - (float)b0[e];
+  const wg_bf16x4 b1 = {(__bf16)r1[0], (__bf16)r1[1], (__bf16)r1[2], (__bf16)r1[3]};
+  f32x4 r2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r2[e] = r1[e] - (float)b1[e];
+  const wg_bf16x4 b2 = {(__bf16)r2[0], (__bf16)r2[1], (__bf16)r2[2], (__bf16)r2[3]};
+  h = __builtin_bit_cast(wg_u32x2, b0);
+  m = __builtin_bit_cast(wg_u32x2, b1);
+  l = __builtin_bit_cast(wg_u32x2, b2);
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradArgs p, int tiles_n, int tiles_c) {
+  constexpr int MK = 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
+  int bid = blockIdx.x;
+  const int ms = bid % p.msplit; bid /= p.msplit;
+  const int tc = bid % tiles_c; bid /= tiles_c;
+  const int tn = bid % tiles_n; bid /= tiles_n;
+  const int tap = bid;
+  const int n0 = tn * 128, c0 = tc * 128, d = p.tap_d[tap];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave >> 1, wc = wave & 1;
+  const int mq = tid & 7, cq = tid >> 3;                       // rows 4 mq .. 4 mq + 3 of a K-step, columns 4 cq .. 4 cq + 3
+  const int chunk = ((p.M + p.msplit - 1) / p.msplit + MK - 1) / MK * MK;
+  const int m_begin = ms * chunk, m_end = min(p.M, m_begin + chunk);
+  const int nk = m_end > m_begin ? (m_end - m_begin + MK - 1) / MK : 0;
+  const bool plain = (p.out_stride == 1 && p.out_off == 0 && p.Lgrid == p.Lout && p.in_stride == 1 && p.Lin == p.Lgrid);
+  const bool y_full = n0 + 4 * cq + 3 < p.N, x_full = c0 + 4 * cq + 3 < p.Cin;
+
+  // (clip, position) of the thread's first row, advanced by 32 rows per K-step
+  int m_cur = m_begin + 4 * mq;
+  int b_cur = m_cur / p.Lgrid, l_cur = m_cur - b_cur * p.Lgrid;
+  f32x4 ry[2][4], rx[2][4];
+  auto gload = [&](const int set) {
+    int b = b_cur, l = l_cur;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 yv = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
+      if (m_cur + j < m_end) {
+        const int orow = plain ? m_cur + j : b * p.Lout + l * p.out_stride + p.out_off;
+        const int ls = l * p.in_stride + d;
+        const float* yp = p.dY + (size_t)orow * p.lddy + n0 + 4 * cq;
+        if (y_full) yv = *reinterpret_cast<const f32x4*>(yp);
+        else for (int k = 0; k < 4; ++k) if (n0 + 4 * cq + k < p.N) yv[k] = yp[k];
+        if ((unsigned)ls < (unsigned)p.Lin) {
+          const float* xp = p.X + (size_t)(b * p.Lin + ls) * p.ldx + c0 + 4 * cq;
+          if (x_full) xv = *reinterpret_cast<const f32x4*>(xp);
+          else for (int k = 0; k < 4; ++k) if (c0 + 4 * cq + k < p.Cin) xv[k] = xp[k];
+        }
+      }
+      ry[set][j] = yv;
+      rx[set][j] = xv;
+      if (++l == p.Lgrid) { l = 0; ++b; }
+    }
+    m_cur += MK;
+    l_cur += MK;
+    while (l_cur >= p.Lgrid) { l_cur -= p.Lgrid; ++b_cur; }
+  };
+  // transpose in registers, split, store: column e of the patch -> LDS row 32 e + cq, bytes 8 mq .. 8 mq + 7 of each plane
+  auto lstore = [&](const int set) {
+#pragma unroll
+    for (int op = 0; op < 2; ++op) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 v = op == 0 ? f32x4{ry[set][0][e], ry[set][1][e], ry[set][2][e], ry[set][3][e]}
+                                : f32x4{rx[set][0][e], rx[set][1][e], rx[set][2][e], rx[set][3][e]};
+        wg_u32x2 h, m, l;
+        wg_split3(v, h, m, l);
+        unsigned char* dst = wg_smem + (op * 128 + 4 * cq + e) * WG_ROW + 8 * mq;
+        *reinterpret_cast<wg_u32x2*>(dst) = h;
+        *reinterpret_cast<wg_u32x2*>(dst + WG_PLANE) = m;
+        *reinterpret_cast<wg_u32x2*>(dst + 2 * WG_PLANE) = l;
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  if (nk > 0) {
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    if (nk > 1) gload(1);
+    if (nk > 2) gload(0);
+    const int frag_off = (lane & 31) * WG_ROW + 16 * (lane >> 5);
+    const unsigned char* Ys = wg_smem + (wn * 64) * WG_ROW + frag_off;
+    const unsigned char* Xs = wg_smem + (128 + wc * 64) * WG_ROW + frag_off;
+    auto stage = [&](const int it, const int nset, const bool store_next) {
+#pragma unroll
+      for (int u = 0; u < MK / 16; ++u) {
+        wg_bf16x8 a[3][2], b[3][2];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            a[pl][i] = *reinterpret_cast<const wg_bf16x8*>(Ys + pl * WG_PLANE + i * 32 * WG_ROW + u * 32);
+            b[pl][i] = *reinterpret_cast<const wg_bf16x8*>(Xs + pl * WG_PLANE + i * 32 * WG_ROW + u * 32);
+          }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            f32x16 c = acc[i][j];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);   // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);
+            acc[i][j] = c;
+          }
+      }
+      __syncthreads();                      // every wave is done reading the stage
+      if (store_next) {
+        lstore(nset);
+        __syncthreads();
+        if (it + 3 < nk) gload(nset);
+      }
+    };
+    int it = 0;
+    for (; it + 2 < nk; it += 2) {
+      stage(it, 1, true);
+      stage(it + 1, 0, true);
+    }
+    if (it + 1 < nk) {
+      stage(it, 1, true);
+      stage(it + 1, 0, false);
+    } else {
+      stage(it, 1, false);
+    }
+  }
+  // D[i][j]: registers = dY columns n, lane & 31 = X columns c (contiguous: the atomics of an instruction cover 128 bytes)
+  float* out = p.dW + (size_t)tap * p.N * p.Cin;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + wc * 64 + j * 32 + (lane & 31);
+      if (c >= p.Cin) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n < p.N) atomicAdd(out + (size_t)n * p.Cin + c, acc[i][j][r]);
+      }
+    }
+}
+
 int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int N, int Cin, int kind, int B, int Lin,
                  hipStream_t s) {
   PT_CHECK(dY && X && dW && N > 0 && Cin > 0 && B > 0 && Lin > 0, "wgrad: bad argument");
@@ -167,12 +340,20 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, 
       else { a.tap_d[0] = 1; a.tap_d[1] = far; a.tap_d[2] = 0; a.tap_d[3] = far; }
     }
     const int base = tiles_n * tiles_c * a.ntaps;
-    int msplit = (1024 + base - 1) / base;
+    // slices of m: the fp32-MFMA kernel runs many small workgroups per CU (1024 or more in flight); the split kernel runs two
+    // 60 KB workgroups per CU, so its slices fill one round of 512 (few tiles: every slice costs 16 K atomics per tile) or two
+    const bool split = option(OPT_SPLIT_BF16) == 1;
+    int msplit = split ? (base <= 32 ? 512 : 1024) / base : (1024 + base - 1) / base;
     const int maxsplit = (a.M + 63) / 64;
     if (msplit > maxsplit) msplit = maxsplit;
     if (msplit < 1) msplit = 1;
     a.msplit = msplit;
-    PT_LAUNCH(wgrad_kernel, dim3(base * msplit), dim3(256), 0, s, a, tiles_n, tiles_c);
+    if (split) {
+      PT_ENSURE_LDS(wgrad_split_kernel, WG_SMEM);
+      PT_LAUNCH(wgrad_split_kernel, dim3(base * msplit), dim3(256), WG_SMEM, s, a, tiles_n, tiles_c);
+    } else {
+      PT_LAUNCH(wgrad_kernel, dim3(base * msplit), dim3(256), 0, s, a, tiles_n, tiles_c);
+    }
   }
   return 0;
 }

@@ -86,6 +86,38 @@ def test_conv_forward_backward(kind, Cin, N, B, L, slope, use_res):
         assert rel_err(_ncl(rd.grad.cpu(), B, N), rr.grad) < TOL
 
 
+@pytest.mark.parametrize("kind,Cin,N,B,L", [(0, 377, 130, 3, 50), (0, 512, 512, 64, 88), (1, 256, 384, 40, 45),
+                                             (3, 129, 256, 9, 37), (4, 256, 131, 16, 21)])
+def test_weight_gradient_kernels_match_float64(kind, Cin, N, B, L, tap_kernel):
+    """pt_train_wgrad directly, under both kernels (fp32 MFMA / three-term bf16 split with the transposing loader): ragged
+    channel counts (partial float4 patches), row counts that are not multiples of the 32-row K-step, several m-slices
+    combined by atomics, every tap geometry."""
+    kt = T._KT[kind]
+    Lout = {0: L, 1: L, 2: L, 3: (L - 2) // 2 + 1, 4: 2 * L}[kind]
+    g = torch.Generator().manual_seed(Cin + N + L)
+    x = torch.randn(B, Cin, L, generator=g)
+    dy = torch.randn(B, N, Lout, generator=g)
+    w = torch.zeros((Cin, N, kt) if kind == 4 else (N, Cin, kt), dtype=torch.float64, requires_grad=True)
+    xr = x.double()
+    if kind == 0:
+        yr = F.conv1d(xr, w[..., :1])
+    elif kind in (1, 2):
+        yr = F.conv1d(xr, w, padding=kt // 2)
+    elif kind == 3:
+        yr = F.conv1d(xr, w, stride=2, padding=1)
+    else:
+        yr = F.conv_transpose1d(xr, w, stride=2, padding=1)
+    yr.backward(dy.double())
+    ref = w.grad if kind != 0 else w.grad[..., :1]
+    xd, dyd = _rows(x).cuda(), _rows(dy).cuda()
+    dw = torch.zeros(kt, N, Cin, device="cuda")
+    L_ = _lib.lib()
+    _lib.check(L_.pt_train_wgrad(_lib.ptr(dyd), dyd.shape[1], _lib.ptr(xd), xd.shape[1], _lib.ptr(dw), N, Cin, kind, B, L,
+                                 _lib.stream()))
+    got = dw.permute(2, 1, 0) if kind == 4 else dw.permute(1, 2, 0)
+    assert rel_err(got.cpu(), ref) < TOL
+
+
 @pytest.mark.parametrize("rows,use_res", [(77, True), (300, False)])
 def test_layer_norm_res(rows, use_res):
     g = torch.Generator().manual_seed(rows)
