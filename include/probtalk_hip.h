@@ -326,6 +326,8 @@ int pt_postprocess_poses(const float* pred, int B, int T, const float* mean, con
  *                        and the weight gradient (pt_train_wgrad) run on the bf16 matrix cores with each fp32 operand
  *                        split into three bf16 terms and six products per pair (fp32 accuracy at 2.7 x the fp32 MFMA
  *                        rate); 0 = the fp32 MFMA kernels
+ *   "sm_rows"            4800 (default) rows up to which a plain bf16 Linear (bias / ReLU, K % 128 == 0) runs on the
+ *                        small-batch kernel (64 x 64 tiles, the operands of the whole K requested up front); 0 = never
  * Unknown names and out-of-range values are errors (non-zero return, pt_last_error). */
 int pt_set_option(const char* name, int value);
 int pt_get_option(const char* name, int* value);

@@ -394,6 +394,7 @@ int launch_gemm_big(const GemmBigArgs& a, hipStream_t s) {
              "gemm_big: zero_to=%d must be a multiple of 8 within the output rows", a.zero_to);
     PT_CHECK(!a.Res || (a.ldr % 4 == 0 && ((uintptr_t)a.Res & 15) == 0), "gemm_big: residual must be 16-byte aligned rows");
     PT_CHECK(!a.pe || (a.pe_period > 0 && ((uintptr_t)a.pe & 31) == 0), "gemm_big: pe table needs a period and 32-byte alignment");
+    if (gemm_sm_wants(a)) return launch_gemm_sm(a, s);   // latency regime
     if (row_ok && !a.pe && !a.Res && a.zero_to == 0) return launch_gemm_row(a, s);
     if (a.K >= 128 && a.N != 512 && a.N <= 8192) return launch_gemm8(a, 6, s);     // 8192: the bias row it keeps in LDS
     if (a.N == 512) return launch_big<128, 512, 2, 4, 64, EPI_STD, 1>(a, 7, s);

@@ -124,6 +124,9 @@ struct GemmBigArgs {
   double flops;
 };
 int launch_gemm_big(const GemmBigArgs& a, hipStream_t s);
+bool gemm_sm_takes(const GemmBigArgs& a);
+bool gemm_sm_wants(const GemmBigArgs& a);
+int launch_gemm_sm(const GemmBigArgs& a, hipStream_t s);
 
 // Fused tail of a decoder sub-layer (gemm_bf16_sub.hip): last Linear -> stylization pre-op -> style Linear -> residual +
 // post-LN -> optional next Linear, rows kept in registers between the products.
@@ -165,6 +168,8 @@ enum Option {
   OPT_ROW2_MIN_ROWS,       // rows from which the two-workgroups-per-CU row kernel is used (default 20480 = 80 rows x 256 CUs)
   OPT_SPLIT_BF16,          // 1 (default): fp32 tap-GEMMs and weight gradients (fp32 mode, PQ-VAE encoder, train step) run on the bf16 MFMA with both
                            // operands split into three bf16 terms, six products (fp32 accuracy, 2.7 x the fp32 MFMA rate); 0: fp32 MFMA
+  OPT_SM_ROWS,             // rows up to which a plain bf16 Linear (bias / ReLU epilogue, K % 128 == 0) runs on the small-batch kernel
+                           // (gemm_bf16_sm.hip: 64 x 64 tiles, operands of the whole K in flight); 0 = never
   OPT_COUNT
 };
 int option(Option o);

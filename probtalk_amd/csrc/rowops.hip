@@ -156,6 +156,36 @@ int launch_add_ln(float* x, const float* y, const float* gamma, const float* bet
   return 0;
 }
 
+// the same with the bf16 residual stream of the bf16 mode (x lives in bf16 only): the small-batch path, where the Linear
+// runs on 64 x 64 tiles and its LayerNorm cannot be an epilogue (gemm_bf16_sm.hip)
+__global__ __launch_bounds__(256) void add_ln_b_kernel(unsigned short* __restrict__ xb, const float* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const bf16x4 xa = *reinterpret_cast<const bf16x4*>(xb + (size_t)row * DM + lane * 4);
+  const bf16x4 xc = *reinterpret_cast<const bf16x4*>(xb + (size_t)row * DM + 256 + lane * 4);
+  Row8 r = load_row(y + (size_t)row * DM, lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r.a[i] += (float)xa[i];
+    r.b[i] += (float)xc[i];
+  }
+  float mean, rstd;
+  ln_stats(r, mean, rstd);
+  const Row8 g = load_row(gamma, lane), b = load_row(beta, lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r.a[i] = (r.a[i] - mean) * rstd * g.a[i] + b.a[i];
+    r.b[i] = (r.b[i] - mean) * rstd * g.b[i] + b.b[i];
+  }
+  store_row_bf16(xb + (size_t)row * DM, lane, r);
+}
+int launch_add_ln_b(unsigned short* xb, const float* y, const float* gamma, const float* beta, int rows, hipStream_t s) {
+  PT_LAUNCH(add_ln_b_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, xb, y, gamma, beta, rows);
+  return 0;
+}
+
 // refiner condition: one-hot(mask) appended as two channels (RTransformer.py:218-219):
 // cond_cl[row][C0] = (mask==0), cond_cl[row][C0+1] = (mask==1), remaining pad columns zero.
 __global__ void mask_onehot_kernel(const float* __restrict__ mask, float* __restrict__ cond, int rows, int ld, int c0,

@@ -18,6 +18,7 @@ int launch_embed_pe(const int* ids, const float* tok, const double* pe, const do
 int launch_ln_mod_silu(const float* h, float* out, unsigned short* outb, const float* gamma, const float* beta,
                        const float* style, const int64_t* label, int n_label, int rows, int rows_per_clip,
                        int n_classes, hipStream_t s);
+int launch_add_ln_b(unsigned short* xb, const float* y, const float* gamma, const float* beta, int rows, hipStream_t s);
 int launch_add_ln(float* x, const float* y, const float* gamma, const float* beta, int rows, unsigned short* xb,
                   hipStream_t s);
 int launch_cvt_f32_bf16(const float* in, int ldi, unsigned short* out, int ldo, int rows, int cols, int zero_to,
@@ -280,7 +281,9 @@ static int lin_b(const DevConv& c, const bf16_t* A, int lda, int rows, float* C,
   PT_CHECK(c.wb != nullptr, "bf16 weights were not packed for this layer");
   PT_CHECK(lda >= c.Kb, "lin_b: input leading dim %d < packed K %d", lda, c.Kb);
   const bool small = c.N != 512 && rows <= option(OPT_SMALL_ROWS);     // few 256 x 256 tiles: the 4-wave kernel's smaller tiles fill more CUs
-  if (!small && c.N >= 256 && c.N % 8 == 0 && (act == ACT_NONE || slope == 0.f)) {
+  // latency regime: the small-batch kernel takes any plain Linear (launch_gemm_big routes it there by the row count)
+  const bool sm = rows <= option(OPT_SM_ROWS) && c.Kb % 128 == 0 && !pe && c.N % 8 == 0 && (act == ACT_NONE || slope == 0.f);
+  if (sm || (!small && c.N >= 256 && c.N % 8 == 0 && (act == ACT_NONE || slope == 0.f))) {
     GemmBigArgs a;
     memset(&a, 0, sizeof(a));
     a.A = A; a.lda = lda; a.W = c.wb; a.bias = c.b; a.M = rows; a.N = c.N; a.K = c.Kb; a.Npad = c.Npad;
@@ -326,10 +329,27 @@ static bool use_fused_tail(const DevConv& last, const StyleW& st, int rows, int 
   return tiles * 100 >= rounds * grid * (last.Kb == DM ? 85 : 90);
 }
 
-static int sublayer_tail_b(const DevConv& last, const bf16_t* A, int lda, bf16_t* tmp, const StyleW& st, const LNW& ln,
+static int sublayer_tail_b(const DevConv& last, const bf16_t* A, int lda, bf16_t* tmp, float* tf, const StyleW& st, const LNW& ln,
                            float* x, bf16_t* xb, int rows, int rows_per_clip, const int64_t* label, int n_label,
                            int n_classes, hipStream_t s) {
   PT_CHECK(last.wb && st.out.wb && last.N == DM && st.out.N == DM && st.out.Kb == DM, "sublayer_tail: unexpected geometry");
+  {
+    // Latency regime (1-16 clips): the two Linears on the small-batch kernel (64 x 64 tiles, 8 workgroups per 64 rows, the
+    // operands of the whole K in flight at once) with fp32 outputs in `tf`, the two normalisations as the fp32 mode's row
+    // kernels behind them: four short launches instead of two whose length is a 3-stage ring walking the whole W.
+    GemmBigArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.W = last.wb; g.bias = last.b; g.M = rows; g.N = DM; g.K = last.Kb; g.Npad = last.Npad;
+    g.epi = EPI_STD; g.C = tf; g.ldc = DM; g.flops = 2.0 * rows * DM * last.Cin;
+    if (tf && gemm_sm_wants(g)) {
+      if (launch_gemm_big(g, s)) return 1;
+      if (launch_ln_mod_silu(tf, nullptr, tmp, st.ln.g, st.ln.b, st.table, label, n_label, rows, rows_per_clip, n_classes, s)) return 1;
+      g.A = tmp; g.lda = DM; g.W = st.out.wb; g.bias = st.out.b; g.K = DM; g.Npad = st.out.Npad; g.flops = 2.0 * rows * DM * DM;
+      if (launch_gemm_big(g, s)) return 1;
+      if (resid_bf16()) return launch_add_ln_b(xb, tf, ln.g, ln.b, rows, s);
+      return launch_add_ln(x, tf, ln.g, ln.b, rows, xb, s);
+    }
+  }
   if (use_fused_tail(last, st, rows, n_classes)) {
     SubArgs f;
     memset(&f, 0, sizeof(f));
@@ -382,12 +402,12 @@ static int decoder_layer(const DecLayer& L, TBufs& b, const void* kv, int B, int
   const bf16_t* kvb = (const bf16_t*)kv;
   if (lin_b(L.sa_in, b.xb, DM, R, nullptr, 0, b.qkvb, 3 * DM, ACT_NONE, 1.f, s)) return 1;
   if (launch_attention_bf16(b.qkvb, 3 * DM, b.qkvb + DM, 3 * DM, b.qkvb + 2 * DM, 3 * DM, b.attb, DM, B, Nq, Nq, NH, s)) return 1;
-  if (sublayer_tail_b(L.sa_out, b.attb, DM, b.hbb, L.st[0], L.n1, b.x, b.xb, R, Nq, label, n_label, n_classes, s)) return 1;
+  if (sublayer_tail_b(L.sa_out, b.attb, DM, b.hbb, b.t, L.st[0], L.n1, b.x, b.xb, R, Nq, label, n_label, n_classes, s)) return 1;
   if (lin_b(L.ca_q, b.xb, DM, R, nullptr, 0, b.qkvb, DM, ACT_NONE, 1.f, s)) return 1;
   if (launch_attention_bf16(b.qkvb, DM, kvb, 2 * DM, kvb + DM, 2 * DM, b.attb, DM, B, Nq, Nk, NH, s)) return 1;
-  if (sublayer_tail_b(L.ca_out, b.attb, DM, b.hbb, L.st[1], L.n2, b.x, b.xb, R, Nq, label, n_label, n_classes, s)) return 1;
+  if (sublayer_tail_b(L.ca_out, b.attb, DM, b.hbb, b.t, L.st[1], L.n2, b.x, b.xb, R, Nq, label, n_label, n_classes, s)) return 1;
   if (lin_b(L.ff1, b.xb, DM, R, nullptr, 0, b.hbb, FF, ACT_LEAKY, 0.f, s)) return 1;
-  return sublayer_tail_b(L.ff2, b.hbb, FF, b.attb, L.st[2], L.n3, b.x, b.xb, R, Nq, label, n_label, n_classes, s);
+  return sublayer_tail_b(L.ff2, b.hbb, FF, b.attb, b.t, L.st[2], L.n3, b.x, b.xb, R, Nq, label, n_label, n_classes, s);
 }
 
 static size_t vt_elems(int B, int Nk) { return (size_t)B * NH * 64 * round_up(Nk, 32); }

@@ -182,6 +182,26 @@ class tap_gemm_kernel:
         return split_bf16 if self.split else fp32_mfma
 
 
+class lib_option:
+    """with lib_option("sm_rows", 0): ... -- sets a run-time switch of the library and restores its previous value."""
+    def __init__(self, name, value):
+        self.name, self.value = name.encode(), value
+
+    def __enter__(self):
+        import ctypes as C
+        from probtalk_amd import _lib
+        old = C.c_int(0)
+        _lib.check(_lib.lib().pt_get_option(self.name, C.byref(old)))
+        self.old = old.value
+        _lib.check(_lib.lib().pt_set_option(self.name, self.value))
+        return self
+
+    def __exit__(self, *exc):
+        from probtalk_amd import _lib
+        _lib.check(_lib.lib().pt_set_option(self.name, self.old))
+        return False
+
+
 def pq_tile_case():
     """Inputs of tests/golden/pq_tile_b8_w11.npz (tools/make_golden_pq_tile.py): batches with FEWER latent chunks than codes
     (configs[0]'s own shape, B=8, T=88 -> 88 rows < 128 codes), so that ProductQuantization._tile (vqvae_modules.py:571-580)

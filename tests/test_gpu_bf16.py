@@ -52,6 +52,27 @@ def test_predictor_logits_bf16():
                lambda: O.tokens_to_logits(sd, ids, lab, cond))
 
 
+def test_small_batch_path_and_fused_path_both_meet_the_bf16_criterion():
+    """Few rows (here 444 token rows) take the latency path: Linears on gemm_sm_kernel, LayerNorms as row kernels behind
+    them (option sm_rows); sm_rows = 0 keeps the fused LayerNorm epilogues of the large-batch path.  Both against the oracle
+    under the one bf16 criterion, and against each other at twice the bf16 rounding of the logits' scale."""
+    from tests.helpers import lib_option
+    pn = _predictor()
+    sd = ref_state_dict("Predictor")
+    B, Tq = 3, 37
+    cond = make_input("bf.cond", (B, 768, Tq))
+    ids = make_input("bf.ids", (B, Tq, 4), "int", low=0, high=129)
+    lab = torch.tensor([0, 2, 3])
+    ref = O.tokens_to_logits(sd, ids, lab, cond)
+    outs = []
+    for sm in (0, 4800):
+        with lib_option("sm_rows", sm):
+            out = pn.decoder.tokens_to_logits(ids.cuda(), lab.cuda(), cond.cuda()).cpu()
+        check_bf16(out, ref, f"predictor logits T'=37, sm_rows={sm}", lambda: O.tokens_to_logits(sd, ids, lab, cond))
+        outs.append(out)
+    assert rel_err(outs[0], outs[1]) < 2e-2
+
+
 def test_predictor_sample_bf16_runs_and_first_pass_matches():
     g = golden("predictor_b2_t88.npz")
     pn = _predictor()

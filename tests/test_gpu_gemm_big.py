@@ -263,3 +263,34 @@ def test_two_workgroups_per_cu_row_kernel_equals_persistent_row_kernel(M, K):
     assert bool((res[0][0][:, 512:] == 7.0).all()) and bool((res[0][1][:, 512:] == 7.0).all())
     for name, a, b in zip(("fp32", "bf16", "lnmod", "addln x", "addln xb", "addln bf16 stream"), res[0], res[1]):
         assert torch.equal(a, b), f"{name}: two-workgroup kernel differs from the persistent row kernel"
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(1408, 512, 512, 0), (1408, 1536, 512, 0), (1408, 2048, 512, 1), (1408, 512, 2048, 0),
+                                        (148, 128, 512, 0), (1, 512, 512, 0), (65, 72, 128, 1), (2368, 376, 1024, 0),
+                                        (3000, 512, 768, 0)])
+def test_small_batch_kernel_matches_reference_and_the_persistent_kernels(M, N, K, relu):
+    """gemm_sm_kernel (option sm_rows: 64 x 64 tiles, the operands of the whole K requested up front, ring of four 128-deep
+    groups beyond K = 512) against float64 and against the kernels it replaces at few rows (sm_rows = 0): ragged M and N, one
+    row, K = 128 (one group) to 2048 (ring wraps three times), both outputs, padded leading dimension untouched."""
+    from tests.helpers import lib_option
+    L = _lib.lib()
+    A, W, bias, Np = _mk(M, N, K, 3 + M + N)
+    ref = A.double() @ W[:N].double().t() + bias[:N].double()
+    if relu:
+        ref = ref.clamp_min(0)
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    ldc = N + 8
+    outs = {}
+    for sm in (0, 1 << 20):
+        with lib_option("sm_rows", sm):
+            C = torch.full((M, ldc), 7.0, device="cuda")
+            Cb = torch.full((M, ldc), 7.0, device="cuda", dtype=torch.bfloat16)
+            _lib.check(L.pt_gemm_bf16(_lib.ptr(Ad), K, _lib.ptr(Wd), _lib.ptr(bd), M, N, K, Np, _lib.ptr(C), ldc,
+                                      _lib.ptr(Cb), ldc, relu, _lib.stream()))
+            torch.cuda.synchronize()
+        scale = float(ref.abs().max())
+        assert float((C[:, :N].cpu().double() - ref).abs().max()) / scale < 2e-6
+        assert float((Cb[:, :N].cpu().double() - ref).abs().max()) / scale < 5e-3
+        assert bool((C[:, N:] == 7.0).all()) and bool((Cb[:, N:] == 7.0).all())
+        outs[sm] = C[:, :N].clone()
+    assert float((outs[0] - outs[1 << 20]).abs().max()) / float(ref.abs().max()) < 2e-6

@@ -20,6 +20,7 @@ OPTIONS = {
     "row2": (0, 1, (-1, 2)),
     "row2_min_rows": (20480, 1, (-1,)),
     "split_bf16": (1, 0, (-1, 2)),
+    "sm_rows": (4800, 0, (-1,)),
 }
 
 
