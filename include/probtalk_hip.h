@@ -328,6 +328,8 @@ int pt_postprocess_poses(const float* pred, int B, int T, const float* mean, con
  *                        rate); 0 = the fp32 MFMA kernels
  *   "sm_rows"            4800 (default) rows up to which a plain bf16 Linear (bias / ReLU, K % 128 == 0) runs on the
  *                        small-batch kernel (64 x 64 tiles, the operands of the whole K requested up front); 0 = never
+ *   "w_ktile"            1 (default) the N = 512 row kernel streams the K-tile-major copy of a model's weights
+ *                        ([K / 32][512][32]: whole cache lines per DMA instruction); 0 = the row-major weights
  * Unknown names and out-of-range values are errors (non-zero return, pt_last_error). */
 int pt_set_option(const char* name, int value);
 int pt_get_option(const char* name, int* value);

@@ -82,11 +82,12 @@ constexpr OptSpec g_opt_spec[pt::OPT_COUNT] = {
     {"row_tile", 0, 0, 10},           {"attn_train_rowwise", 0, 0, 1}, {"conv8", 1, 0, 1},
     {"store_overlap", 1, 0, 1},       {"row2", 0, 0, 1},         {"row2_min_rows", 20480, 0, 1 << 30},
     {"split_bf16", 1, 0, 1},          {"sm_rows", 4800, 0, 1 << 30},
+    {"w_ktile", 1, 0, 1},
 };
 int g_opt[pt::OPT_COUNT] = {g_opt_spec[0].def, g_opt_spec[1].def, g_opt_spec[2].def, g_opt_spec[3].def, g_opt_spec[4].def,
                             g_opt_spec[5].def, g_opt_spec[6].def, g_opt_spec[7].def, g_opt_spec[8].def, g_opt_spec[9].def,
-                            g_opt_spec[10].def};
-static_assert(pt::OPT_COUNT == 11, "option table out of step with pt_common.h");
+                            g_opt_spec[10].def, g_opt_spec[11].def};
+static_assert(pt::OPT_COUNT == 12, "option table out of step with pt_common.h");
 int find_option(const char* name) {
   if (name)
     for (int i = 0; i < pt::OPT_COUNT; ++i)

@@ -29,6 +29,7 @@ struct DevConv {
   int merged = 1;       // 2 when a residual conv was folded in (the reference runs two convs)
   unsigned short* wb = nullptr;  // bf16 copy [slabs][Npad][Kb] (bf16-mode models)
   int Kb = 0;                    // round_up(Cin, 64)
+  unsigned short* wbt = nullptr; // N = 512 Linears: the same weights K-tile-major, [Kb / 32][512][32] (gemm_bf16_row.hip)
 };
 
 enum ConvKind { CONV_K1, CONV_K3, CONV_K7, CONV_DOWN, CONV_UP };

@@ -108,6 +108,7 @@ struct GemmBigArgs {
   const float* bias;                  // [N]
   int M, N, K, Npad;
   int epi;
+  const unsigned short* Wt;           // optional (row kernel only): W K-tile-major, [K / 32][512][32]; same values as W
   // EPI_STD: C fp32 and/or Cb bf16 = act(A.W^T + bias (+pe fp64) (+Res))
   float* C; int ldc;
   unsigned short* Cb; int ldcb;       // bf16 output (all epilogues)
@@ -170,6 +171,7 @@ enum Option {
                            // operands split into three bf16 terms, six products (fp32 accuracy, 2.7 x the fp32 MFMA rate); 0: fp32 MFMA
   OPT_SM_ROWS,             // rows up to which a plain bf16 Linear (bias / ReLU epilogue, K % 128 == 0) runs on the small-batch kernel
                            // (gemm_bf16_sm.hip: 64 x 64 tiles, operands of the whole K in flight); 0 = never
+  OPT_W_KTILE,             // 1 (default): the row kernel reads the K-tile-major copy of an N = 512 Linear's weights where the model has one; 0: row-major
   OPT_COUNT
 };
 int option(Option o);

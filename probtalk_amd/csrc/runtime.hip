@@ -117,6 +117,15 @@ static int pack_conv(Model& m, DevConv& out, const std::string& w1, const std::s
           hwb[((size_t)k * out.Npad + n) * out.Kb + c] = (unsigned short)(u >> 16);
         }
     if (upload(m, hwb, &out.wb)) return 1;
+    if (kt == 1 && out.N == 512 && out.Npad == 512) {
+      // K-tile-major copy for the row kernel: its staging ring takes W 32 columns of k at a time, i.e. 64 bytes of every
+      // row; in this order a DMA instruction's 16 rows x 64 B are 1 KB of consecutive memory (whole cache lines)
+      std::vector<unsigned short> hwt((size_t)out.Npad * out.Kb);
+      for (int t = 0; t < out.Kb / 32; ++t)
+        for (int n = 0; n < out.Npad; ++n)
+          memcpy(&hwt[((size_t)t * out.Npad + n) * 32], &hwb[(size_t)n * out.Kb + t * 32], 64);
+      if (upload(m, hwt, &out.wbt)) return 1;
+    }
   }
   return upload(m, hb, &out.b);
 }

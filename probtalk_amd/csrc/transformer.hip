@@ -286,7 +286,7 @@ static int lin_b(const DevConv& c, const bf16_t* A, int lda, int rows, float* C,
   if (sm || (!small && c.N >= 256 && c.N % 8 == 0 && (act == ACT_NONE || slope == 0.f))) {
     GemmBigArgs a;
     memset(&a, 0, sizeof(a));
-    a.A = A; a.lda = lda; a.W = c.wb; a.bias = c.b; a.M = rows; a.N = c.N; a.K = c.Kb; a.Npad = c.Npad;
+    a.A = A; a.lda = lda; a.W = c.wb; a.Wt = c.wbt; a.bias = c.b; a.M = rows; a.N = c.N; a.K = c.Kb; a.Npad = c.Npad;
     a.epi = EPI_STD; a.C = C; a.ldc = ldc; a.Cb = Cb; a.ldcb = ldcb; a.pe = pe; a.pe_period = period;
     a.relu = act == ACT_LEAKY;
     a.flops = 2.0 * rows * c.N * c.Cin;
@@ -360,13 +360,13 @@ static int sublayer_tail_b(const DevConv& last, const bf16_t* A, int lda, bf16_t
   }
   GemmBigArgs a;
   memset(&a, 0, sizeof(a));
-  a.A = A; a.lda = lda; a.W = last.wb; a.bias = last.b; a.M = rows; a.N = DM; a.K = last.Kb; a.Npad = last.Npad;
+  a.A = A; a.lda = lda; a.W = last.wb; a.Wt = last.wbt; a.bias = last.b; a.M = rows; a.N = DM; a.K = last.Kb; a.Npad = last.Npad;
   a.epi = EPI_LNMOD; a.Cb = tmp; a.ldcb = DM; a.style = st.fold;
   a.label = label; a.n_label = n_label; a.rows_per_clip = rows_per_clip; a.n_classes = n_classes;
   a.flops = 2.0 * rows * DM * last.Cin;
   if (launch_gemm_big(a, s)) return 1;
   memset(&a, 0, sizeof(a));
-  a.A = tmp; a.lda = DM; a.W = st.out.wb; a.bias = st.out.b; a.M = rows; a.N = DM; a.K = DM; a.Npad = st.out.Npad;
+  a.A = tmp; a.lda = DM; a.W = st.out.wb; a.Wt = st.out.wbt; a.bias = st.out.b; a.M = rows; a.N = DM; a.K = DM; a.Npad = st.out.Npad;
   a.epi = EPI_ADDLN; a.X = resid_bf16() ? nullptr : x; a.Cb = xb; a.ldcb = DM; a.gamma = ln.g; a.beta = ln.b;
   a.flops = 2.0 * rows * DM * DM;
   return launch_gemm_big(a, s);

@@ -73,6 +73,23 @@ def test_small_batch_path_and_fused_path_both_meet_the_bf16_criterion():
     assert rel_err(outs[0], outs[1]) < 2e-2
 
 
+def test_ktile_major_weights_give_the_same_bits_as_row_major_weights():
+    """The row kernel streams an N = 512 Linear's weights from a K-tile-major copy ([K/32][512][32], option w_ktile = 1) or
+    from the row-major matrix (0): same values, same order of accumulation, so the logits must agree bit for bit (9,472
+    token rows: the persistent multi-tile row kernels, K = 512 and 2048)."""
+    from tests.helpers import lib_option
+    pn = _predictor()
+    B, Tq = 64, 37
+    cond = make_input("kt.cond", (B, 768, Tq))
+    ids = make_input("kt.ids", (B, Tq, 4), "int", low=0, high=129)
+    lab = torch.arange(B) % 4
+    outs = []
+    for v in (1, 0):
+        with lib_option("w_ktile", v):
+            outs.append(pn.decoder.tokens_to_logits(ids.cuda(), lab.cuda(), cond.cuda()).cpu())
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_predictor_sample_bf16_runs_and_first_pass_matches():
     g = golden("predictor_b2_t88.npz")
     pn = _predictor()

@@ -21,6 +21,7 @@ OPTIONS = {
     "row2_min_rows": (20480, 1, (-1,)),
     "split_bf16": (1, 0, (-1, 2)),
     "sm_rows": (4800, 0, (-1,)),
+    "w_ktile": (1, 0, (-1, 2)),
 }
 
 
