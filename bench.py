@@ -211,6 +211,29 @@ def train_bench(a, rank, world, dev):
                                   "PredictorNet train forward with dropout 0.1, cross-entropy, backward, clip, AdamW)",
                       "clips_per_step_per_gpu": B, "frames_per_clip": T, "last_loss": ld["loss"],
                       "parallelism": f"dp{world}: clips sharded over ranks, bucketed gradient all-reduce over RCCL"}}
+    if rank == 0 and not a.no_roofline and (world == 1 or a.roofline):
+        # dominant kernel of the step: the fp32 tap-GEMM (forward + input gradients), every launch of one extra, untimed step
+        # bracketed by HIP events on its stream; the weight-gradient kernel's own figures: profiles/r3/wgrad_split_bf16.txt
+        from probtalk_amd import _lib
+        L = _lib.lib()
+        torch.cuda.synchronize()
+        _lib.check(L.pt_prof_enable(1))
+        pred(bat)
+        torch.cuda.synchronize()
+        ms, fl, ln = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int * 8)()
+        _lib.check(L.pt_prof_read(ms, fl, ln))
+        _lib.check(L.pt_prof_enable(0))
+        tot_ms, tot_fl, tot_n = sum(ms[i] for i in range(3)), sum(fl[i] for i in range(3)), sum(ln[i] for i in range(3))
+        peak, kname = f32_peak()
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                           "kernel": kname + ": forward and input-gradient launches of one train step",
+                           "launches_per_step": tot_n, "avg_launch_ms": tot_ms / max(tot_n, 1), "kernel_ms_per_step": tot_ms,
+                           "algorithmic_gflop_per_launch": tot_fl / max(tot_n, 1) / 1e9,
+                           "timed_as": "HIP events around every tap-GEMM launch of one untimed extra step; rocprofv3 summary: "
+                                       "profiles/r3/train_kernel_stats.csv"}
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         print(json.dumps(res), flush=True)
 
