@@ -210,6 +210,11 @@ int pt_embed_pe(const int32_t* ids, const float* tok, const double* pe, const do
  * sum over rows of dY[row][n] * X[tap-shifted row][c] */
 int pt_train_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int N, int Cin, int kind, int B, int Lin,
                    void* stream);
+/* the same plus the bias gradient db[N] (pre-zeroed) = column sums of dY (nn.Conv1d / nn.Linear .bias.grad): accumulated
+ * inside the weight-gradient kernel from the dY tiles it stages anyway (option split_bf16 = 1), else pt_train_colsum's
+ * launch behind it. */
+int pt_train_wgrad_bias(const float* dY, int lddy, const float* X, int ldx, float* dW, float* db, int N, int Cin, int kind, int B,
+                        int Lin, void* stream);
 /* out[c] += sum_rows a[row][c] (* b[row][c] if b): bias gradients */
 int pt_train_colsum(const float* a, int lda, const float* b, int ldb, int rows, int cols, float* out, void* stream);
 /* nn.LayerNorm(512) on x (+ res): y, stats[rows][2] = mean, rstd; backward gives dx (w.r.t. x + res), dgamma, dbeta (+=) */

@@ -65,6 +65,7 @@ def _proto(lib):
     f, u64, sz = C.c_float, C.c_uint64, C.c_size_t
     lib.pt_embed_pe.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
     lib.pt_train_wgrad.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, vp]
+    lib.pt_train_wgrad_bias.argtypes = [vp, i, vp, i, vp, vp, i, i, i, i, i, vp]
     lib.pt_train_colsum.argtypes = [vp, i, vp, i, i, i, vp, vp]
     lib.pt_train_ln_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, vp]
     lib.pt_train_ln_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, vp]
@@ -110,7 +111,7 @@ EXPORTS = [
     "pt_refiner_workspace_bytes", "pt_refiner_forward", "pt_interp_blend", "pt_conv1d_cl", "pt_ncl_to_cl",
     "pt_cl_to_ncl", "pt_pq_search_cl", "pt_pq_gather_cl", "pt_attention_cl", "pt_attention_bf16", "pt_gemm_bf16", "pt_gemm_bf16_lnmod",
     "pt_gemm_bf16_addln", "pt_gemm_bf16_sublayer", "pt_permute_k32", "pt_conv1d_cl_bf16", "pt_postprocess_poses", "pt_prof_enable",
-    "pt_prof_read", "pt_embed_pe", "pt_train_wgrad", "pt_train_colsum", "pt_train_ln_fwd", "pt_train_ln_bwd",
+    "pt_prof_read", "pt_embed_pe", "pt_train_wgrad", "pt_train_wgrad_bias", "pt_train_colsum", "pt_train_ln_fwd", "pt_train_ln_bwd",
     "pt_train_modsilu_fwd", "pt_train_modsilu_bwd", "pt_train_attention_fwd", "pt_train_attention_bwd",
     "pt_train_cross_entropy", "pt_train_bn_fwd", "pt_train_bn_bwd", "pt_train_act_bwd", "pt_train_gate_fwd",
     "pt_train_gate_bwd", "pt_train_embed_bwd", "pt_train_dropout", "pt_train_sumsq", "pt_train_clip_coef",

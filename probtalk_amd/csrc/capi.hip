@@ -15,7 +15,7 @@ struct pt_model {
 };
 
 namespace pt {
-int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int N, int Cin, int kind, int B, int Lin, hipStream_t s);
+int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, float* db, int N, int Cin, int kind, int B, int Lin, hipStream_t s);
 int launch_colsum(const float* a, int lda, const float* b, int ldb, int rows, int cols, float* out, hipStream_t s);
 int launch_ln_fwd(const float* x, const float* res, const float* g, const float* b, float* y, float* stats, int rows, hipStream_t s);
 int launch_ln_bwd(const float* dy, const float* x, const float* res, const float* stats, const float* g, float* dx, float* dg, float* db, int rows, hipStream_t s);
@@ -456,7 +456,12 @@ int pt_embed_pe(const int32_t* ids, const float* tok, const double* pe, const do
   return launch_embed_pe(ids, tok, pe, ppe, x, nullptr, rows, N, G, vocab, (hipStream_t)stream);
 }
 int pt_train_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int N, int Cin, int kind, int B, int Lin,
-                   void* stream) { return launch_wgrad(dY, lddy, X, ldx, dW, N, Cin, kind, B, Lin, (hipStream_t)stream); }
+                   void* stream) { return launch_wgrad(dY, lddy, X, ldx, dW, nullptr, N, Cin, kind, B, Lin, (hipStream_t)stream); }
+int pt_train_wgrad_bias(const float* dY, int lddy, const float* X, int ldx, float* dW, float* db, int N, int Cin, int kind, int B,
+                        int Lin, void* stream) {
+  PT_CHECK(db != nullptr, "pt_train_wgrad_bias: db is null (use pt_train_wgrad)");
+  return launch_wgrad(dY, lddy, X, ldx, dW, db, N, Cin, kind, B, Lin, (hipStream_t)stream);
+}
 int pt_train_colsum(const float* a, int lda, const float* b, int ldb, int rows, int cols, float* out, void* stream) {
   return launch_colsum(a, lda, b, ldb, rows, cols, out, (hipStream_t)stream);
 }

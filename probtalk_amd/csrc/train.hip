@@ -56,6 +56,7 @@ struct WgradArgs {
   int tap_d[MAX_TAPS];
   int M, Lgrid, Lin, Lout, in_stride, out_stride, out_off;
   int msplit;
+  float* db;                     // optional (split kernel): bias gradient = column sums of dY, accumulated by the workgroups of tap 0 / c-tile 0
 };
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, int tiles_n, int tiles_c) {
@@ -217,7 +218,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradArgs p, 
     while (l_cur >= p.Lgrid) { l_cur -= p.Lgrid; ++b_cur; }
   };
   // transpose in registers, split, store: column e of the patch -> LDS row 32 e + cq, bytes 8 mq .. 8 mq + 7 of each plane
+  const bool do_db = p.db != nullptr && tap == 0 && tc == 0;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
   auto lstore = [&](const int set) {
+    if (do_db) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cs[e] += (ry[set][0][e] + ry[set][1][e]) + (ry[set][2][e] + ry[set][3][e]);
+    }
 #pragma unroll
     for (int op = 0; op < 2; ++op) {
 #pragma unroll
@@ -295,6 +302,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradArgs p, 
       stage(it, 1, false);
     }
   }
+  if (do_db) {
+    // the thread's 4 columns over its rows; the 8 row groups of a column quad are 8 adjacent lanes
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = cs[e];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      if (mq == 0 && n0 + 4 * cq + e < p.N) atomicAdd(p.db + n0 + 4 * cq + e, v);
+    }
+  }
   // D[i][j]: registers = dY columns n, lane & 31 = X columns c (contiguous: the atomics of an instruction cover 128 bytes)
   float* out = p.dW + (size_t)tap * p.N * p.Cin;
 #pragma unroll
@@ -311,13 +329,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradArgs p, 
     }
 }
 
-int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int N, int Cin, int kind, int B, int Lin,
+int launch_colsum(const float* a, int lda, const float* b, int ldb, int rows, int cols, float* out, hipStream_t s);
+// db (optional, pre-zeroed [N]): the bias gradient, column sums of dY.  The split kernel accumulates it from the dY tiles it
+// stages anyway (the workgroups of tap 0 and c-tile 0); with the fp32-MFMA kernel it is the column-sum kernel's launch.
+int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, float* db, int N, int Cin, int kind, int B, int Lin,
                  hipStream_t s) {
   PT_CHECK(dY && X && dW && N > 0 && Cin > 0 && B > 0 && Lin > 0, "wgrad: bad argument");
   PT_CHECK(lddy % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0, "wgrad: rows must be 16-byte aligned");
   WgradArgs a;
   memset(&a, 0, sizeof(a));
   a.dY = dY; a.lddy = lddy; a.X = X; a.ldx = ldx; a.dW = dW; a.N = N; a.Cin = Cin;
+  a.db = option(OPT_SPLIT_BF16) == 1 ? db : nullptr;
   a.Lin = Lin; a.in_stride = 1; a.out_stride = 1; a.out_off = 0;
   int launches = 1;
   switch (kind) {
@@ -355,6 +377,7 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, 
       PT_LAUNCH(wgrad_kernel, dim3(base * msplit), dim3(256), 0, s, a, tiles_n, tiles_c);
     }
   }
+  if (db && !a.db) return launch_colsum(dY, lddy, nullptr, 0, B * a.Lout, N, db, s);
   return 0;
 }
 

@@ -7,6 +7,7 @@ All activations are channels-last 2-D fp32 tensors `[B*L, C]` with C a multiple 
 of the inference library.  Conv `kind`: 0 = Linear / 1x1, 1 = k3 s1 p1, 2 = k7 s1 p3, 3 = k4 s2 p1, 4 = ConvTranspose
 k4 s2 p1 (reference shapes: nets/spg/vqvae_modules.py:107-200, nets/inpainting/gated_pixelcnn_1d.py:39-83).
 """
+import os
 import torch
 
 from . import _lib
@@ -112,13 +113,21 @@ class ConvCL(torch.autograd.Function):
                 t = _zeros(x.shape)
                 t[:, :min(dx.shape[1], x.shape[1])] = dx[:, :min(dx.shape[1], x.shape[1])]
                 dx = t
+        want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             kt = _KT[kind]
             dwp = _zeros(kt, N, Cin)
-            check(L.pt_train_wgrad(ptr(dy), dy.shape[1], ptr(x), x.shape[1], ptr(dwp), N, Cin, kind, B, Lin, stream()))
+            if want_db:
+                # the bias gradient rides on the weight-gradient kernel (it stages the dY tiles anyway)
+                db = _zeros(N)
+                check(L.pt_train_wgrad_bias(ptr(dy), dy.shape[1], ptr(x), x.shape[1], ptr(dwp), ptr(db), N, Cin, kind, B, Lin,
+                                            stream()))
+                want_db = False
+            else:
+                check(L.pt_train_wgrad(ptr(dy), dy.shape[1], ptr(x), x.shape[1], ptr(dwp), N, Cin, kind, B, Lin, stream()))
             dw = dwp.permute(2, 1, 0) if kind == 4 else dwp.permute(1, 2, 0)
             dw = dw.contiguous() if wdim == 3 else dw.reshape(N, Cin).contiguous()
-        if has_bias and ctx.needs_input_grad[2]:
+        if want_db:
             db = _zeros(N)
             check(L.pt_train_colsum(ptr(dy), dy.shape[1], None, 0, dy.shape[0], N, ptr(db), stream()))
         if has_res and ctx.needs_input_grad[3]:
