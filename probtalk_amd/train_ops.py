@@ -7,7 +7,6 @@ All activations are channels-last 2-D fp32 tensors `[B*L, C]` with C a multiple 
 of the inference library.  Conv `kind`: 0 = Linear / 1x1, 1 = k3 s1 p1, 2 = k7 s1 p3, 3 = k4 s2 p1, 4 = ConvTranspose
 k4 s2 p1 (reference shapes: nets/spg/vqvae_modules.py:107-200, nets/inpainting/gated_pixelcnn_1d.py:39-83).
 """
-import os
 import torch
 
 from . import _lib
