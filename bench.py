@@ -309,9 +309,11 @@ def main():
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--dtype", choices=("bf16", "f32"), default="bf16",
                     help="arithmetic of the predictor/refiner transformers (PQ-VAE encode and code search always fp32)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=None,
                     help="HIP streams the step's clips are split over (contiguous shares, joined before the step returns); "
-                         "1 = the whole batch as one launch sequence")
+                         "1 = the whole batch as one launch sequence.  Default: 2 above 256 clips per step (the streams fill each "
+                         "other's partly filled rounds of tiles: 50.2 vs 53.4 ms at 384 clips), 1 up to there (measured equal at "
+                         "256, 31.2 vs 29.6 ms at 192, 10.3 vs 6.2 ms at 2 clips: small launches are latency-bound)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from one captured HIP graph (probtalk_amd/graphs.py): for small, launch-bound batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -383,6 +385,8 @@ def main():
     ids = torch.randint(0, 4, (B,), device=dev, generator=g)
     gather = OutputGatherer(world, (B, 376, T), dev) if world > 1 else None
 
+    if a.streams is None:
+        a.streams = 2 if B > 256 else 1
     graphed = None
     if a.graph:
         from probtalk_amd.graphs import GraphedHolisticStep
